@@ -1,0 +1,184 @@
+"""Generate golden fixtures by RUNNING the reference's own code in the build container.
+
+Run from the repo root, only where `/root/reference` exists (never on the GPU box):
+
+    python tests/golden/make_golden.py
+
+What runs for real: the reference's icosphere hierarchy, `filter_mesh`,
+`get_edges_from_faces`, `radius_query_indices`, `create_encoding_graph`,
+`create_processing_graph` (+ edge features), static node features, `weighted_mse_loss`,
+`get_lat_weights`, `update_attention_threshold`, and the pydantic parsing of the experiment
+configs.  Modules that are absent from this image (`trimesh`, `torch_geometric`, `wandb`) get
+inert placeholder entries in `sys.modules` so that the reference's top-level `import` lines
+pass; nothing from a placeholder is ever called, so `create_decoding_graph` and every
+PyG-backed layer are NOT covered by these fixtures (their parity is "unpinned").
+
+Outputs (data only - arrays and numbers, no reference source text):
+  tests/golden/graph_64x32_L0.npz      full edge lists + static feats, mesh levels [0]
+  tests/golden/graph_64x32_L12.npz     same, levels [1,2]
+  tests/golden/graph_summary.json      shapes, sha256 prefixes and degree histograms, cfg A and B
+  tests/golden/loss_vectors.npz        (pred, target, lat_w) -> loss, lat weights, threshold schedule
+  tests/golden/config_parse.json       selected fields of the parsed reference configs
+"""
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _placeholders():
+    class _Inert:  # base class stand-in so `class X(GATConv)` statements evaluate
+        def __init__(self, *a, **k):
+            raise RuntimeError("placeholder for a module that is absent from this image")
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    mod("trimesh")
+    mod("wandb")
+    mod("torch_geometric")
+    mod("torch_geometric.nn", GCNConv=_Inert, SimpleConv=_Inert, GATConv=_Inert, LayerNorm=_Inert, summary=None)
+    mod("torch_geometric.utils", dense_to_sparse=None, softmax=None, scatter=None)
+
+
+def _h(t) -> str:
+    a = t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def _graphs(ref, nlat, nlon, levels, radius_q):
+    from src.config import GraphBuildingConfig
+
+    gc = GraphBuildingConfig(
+        grid2mesh_edge_creation="radius", mesh2grid_edge_creation="contained",
+        grid2mesh_radius_query=radius_q, mesh_levels=levels,
+    )
+    lats = np.linspace(-90, 90, nlat, endpoint=True).astype(np.float32)
+    lons = np.linspace(0, 360, nlon, endpoint=False).astype(np.float32)
+    meshes = ref["hier"](splits=max(levels))
+    finest = meshes[-1]
+    mlat, mlon = ref["latlon"](finest_mesh=finest)
+    mlat, mlon = mlat.astype(np.float32), mlon.astype(np.float32)
+    G = nlat * nlon
+    enc, gfeat, mfeat = ref["enc"](
+        grid_node_lats=lats, grid_node_longs=lons, mesh_node_lats=mlat, mesh_node_longs=mlon,
+        mesh=finest, graph_building_config=gc, num_grid_nodes=G,
+    )
+    proc, efeat = ref["proc"](meshes=meshes, mesh_levels=levels, mesh_node_lats=mlat, mesh_node_longs=mlon)
+    return dict(
+        G=G, M=len(finest.vertices), vertices=finest.vertices, faces=finest.faces,
+        mesh_lat=mlat, mesh_lon=mlon, enc=enc, proc=proc, gfeat=gfeat, mfeat=mfeat, efeat=efeat,
+    )
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference tree not present; fixtures can only be regenerated in the build container")
+    _placeholders()
+    sys.path.insert(0, REF)
+    from src.create_graphs import create_encoding_graph, create_processing_graph
+    from src.mesh.create_mesh import get_hierarchy_of_triangular_meshes_for_sphere
+    from src.utils import get_mesh_lat_long
+
+    ref = dict(hier=get_hierarchy_of_triangular_meshes_for_sphere, latlon=get_mesh_lat_long,
+               enc=create_encoding_graph, proc=create_processing_graph)
+
+    # --- full small graphs -------------------------------------------------------------
+    for tag, levels in (("L0", [0]), ("L12", [1, 2])):
+        g = _graphs(ref, 32, 64, levels, 0.5)
+        np.savez_compressed(
+            os.path.join(HERE, f"graph_64x32_{tag}.npz"),
+            G=g["G"], M=g["M"], levels=np.array(levels), radius_q=0.5,
+            vertices=g["vertices"], faces=g["faces"], mesh_lat=g["mesh_lat"], mesh_lon=g["mesh_lon"],
+            enc_edge_index=g["enc"].numpy(), proc_edge_index=g["proc"].numpy(),
+            grid_static=g["gfeat"].numpy(), mesh_static=g["mfeat"].numpy(), edge_feats=g["efeat"].numpy(),
+        )
+
+    # --- summaries for the benchmark configs -------------------------------------------
+    summary = {}
+    for tag, (nlat, nlon, levels, rq) in {
+        "64x32_L0": (32, 64, [0], 0.5),
+        "64x32_L12": (32, 64, [1, 2], 0.5),
+        "64x32_L35": (32, 64, [3, 5], 0.5),
+        "512x256_L46": (256, 512, [4, 6], 0.6),
+    }.items():
+        g = _graphs(ref, nlat, nlon, levels, rq)
+        G, M = g["G"], g["M"]
+        enc, proc = g["enc"].numpy(), g["proc"].numpy()
+        enc_indeg = np.bincount(enc[1] - G, minlength=M)
+        proc_indeg = np.bincount(proc[1], minlength=M)
+        summary[tag] = dict(
+            G=int(G), M=int(M), E_G2M=int(enc.shape[1]), E_M=int(proc.shape[1]),
+            enc_hash=_h(g["enc"]), proc_hash=_h(g["proc"]),
+            grid_static_hash=_h(g["gfeat"]), mesh_static_hash=_h(g["mfeat"]), edge_feat_hash=_h(g["efeat"]),
+            enc_indeg_hist={str(k): int(v) for k, v in zip(*np.unique(enc_indeg, return_counts=True))},
+            proc_indeg_hist={str(k): int(v) for k, v in zip(*np.unique(proc_indeg, return_counts=True))},
+            enc_sender_sorted=bool((np.diff(enc[0]) >= 0).all()),
+            grid_nodes_without_out_edge=int(G - np.unique(enc[0]).shape[0]),
+            vertices_checksum=float(np.abs(g["vertices"].astype(np.float64)).sum()),
+            mesh_static_checksum=float(np.abs(g["mfeat"].numpy().astype(np.float64)).sum()),
+            grid_static_checksum=float(np.abs(g["gfeat"].numpy().astype(np.float64)).sum()),
+            edge_feat_checksum=float(np.abs(g["efeat"].numpy().astype(np.float64)).sum()),
+            enc_index_checksum=[int(enc[0].astype(np.int64).sum()), int(enc[1].astype(np.int64).sum())],
+            proc_index_checksum=[int((proc[0].astype(np.int64) * np.arange(proc.shape[1])).sum()),
+                                 int((proc[1].astype(np.int64) * np.arange(proc.shape[1])).sum())],
+        )
+    with open(os.path.join(HERE, "graph_summary.json"), "w") as fh:
+        json.dump(summary, fh, indent=1, sort_keys=True)
+
+    # --- loss / schedule vectors ---------------------------------------------------------
+    from src.train import get_lat_weights, update_attention_threshold, weighted_mse_loss, build_boundary_mask
+
+    gen = torch.Generator().manual_seed(1234)
+    B, nlat, nlon, C = 3, 32, 64, 5
+    pred = torch.randn(B, nlat * nlon, C, generator=gen)
+    target = pred + 0.1 * torch.randn(B, nlat * nlon, C, generator=gen)
+    lat_w = get_lat_weights(nlat, nlon, "cpu")
+    chan = torch.tensor([1.0, 1.0, 0.0, 1.0, 0.5])
+    smask = build_boundary_mask(nlon, nlat, 2, "cpu")
+    np.savez_compressed(
+        os.path.join(HERE, "loss_vectors.npz"),
+        pred=pred.numpy(), target=target.numpy(), lat_w=lat_w.numpy(), chan_mask=chan.numpy(),
+        spatial_mask=smask.numpy(),
+        loss_plain=weighted_mse_loss(pred, target).item(),
+        loss_lat=weighted_mse_loss(pred, target, lat_w).item(),
+        loss_lat_chan=weighted_mse_loss(pred, target, lat_w, chan).item(),
+        loss_all=weighted_mse_loss(pred, target, lat_w, chan, smask).item(),
+        thr_epochs=np.arange(0, 40),
+        thr_values=np.array([update_attention_threshold(e) for e in range(40)], dtype=np.float64),
+    )
+
+    # --- config parsing ------------------------------------------------------------------
+    from src.config import ExperimentConfig
+
+    parsed = {}
+    for exp in ("baseline", "attention", "sparse_attention", "wb2_512x256_19f_ar"):
+        with open(os.path.join(REF, "experiments", exp, "config.json")) as fh:
+            cfg = ExperimentConfig(**json.load(fh))
+        parsed[exp] = dict(
+            mesh_levels=cfg.graph.mesh_levels, radius=cfg.graph.grid2mesh_radius_query,
+            enc_mlp_ln=cfg.pipeline.encoder.mlp.use_layer_norm,
+            proc_type=cfg.pipeline.processor.gcn.layer_type.value,
+            proc_ln=cfg.pipeline.processor.gcn.use_layer_norm,
+            dec_mlp_ln=cfg.pipeline.decoder.mlp.use_layer_norm,
+            features=cfg.data.num_features_used, obs=cfg.data.obs_window_used,
+            flattened=cfg.data.want_feats_flattened, max_ar_steps=cfg.max_ar_steps,
+            wandb_log=cfg.wandb_log,
+        )
+    with open(os.path.join(HERE, "config_parse.json"), "w") as fh:
+        json.dump(parsed, fh, indent=1, sort_keys=True)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
