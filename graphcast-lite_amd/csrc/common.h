@@ -1,0 +1,63 @@
+// Shared helpers for libgcl_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gcl.h"
+
+namespace gcl {
+
+void set_error(const char* fmt, ...);
+
+#define GCL_CHECK_ARG(cond, ...)        \
+  do {                                  \
+    if (!(cond)) {                      \
+      gcl::set_error(__VA_ARGS__);      \
+      return GCL_EINVAL;                \
+    }                                   \
+  } while (0)
+
+#define GCL_CHECK_HIP(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      gcl::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return GCL_EHIP;                                                                   \
+    }                                                                                    \
+  } while (0)
+
+#define GCL_CHECK_LAUNCH()                                                     \
+  do {                                                                         \
+    hipError_t _e = hipGetLastError();                                         \
+    if (_e != hipSuccess) {                                                    \
+      gcl::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+      return GCL_EHIP;                                                         \
+    }                                                                          \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+constexpr int kWave = 64;     // CDNA wavefront
+constexpr int kNumXCD = 8;    // MI355X: 8 XCDs, blocks are dealt round-robin over them
+constexpr int kNumCU = 256;
+
+__device__ __forceinline__ float prelu_f(float x, float a) { return x > 0.f ? x : a * x; }
+
+}  // namespace gcl
+
+// Device-side graph arrays (owned by the handle).
+struct gcl_graph {
+  int32_t n = 0;
+  int64_t e = 0;  // E'
+  int32_t kind = 0;
+  int32_t max_in_deg = 0;
+  int32_t max_out_deg = 0;
+  int32_t *rowptr = nullptr, *col = nullptr, *eperm = nullptr;
+  int32_t *trowptr = nullptr, *tcol = nullptr, *tslot = nullptr;
+  float *w = nullptr, *tw = nullptr;
+  // host copy of the PyG-order edge list with loops (for export / prune)
+  int64_t* h_edges = nullptr;  // [2, e]
+};

@@ -1,0 +1,461 @@
+// GATConv(heads=H, concat=False) attention + aggregation, forward and backward, and the
+// SparseGATConv prune.  Reference call sites: src/models.py:425 (GATConv), :130-151 (SparseGATConv);
+// arithmetic per SURVEY.md Appendix A.2 (PyG 2.5.3):
+//   e_ij = LeakyReLU_0.2(a_s[j] + a_d[i]);  alpha = softmax over in-edges of i (segment max
+//   subtracted, +1e-16 in the denominator);  y[i] = mean_h sum_e alpha_e h[j_e,h,:] + bias.
+//
+// Mapping: a destination row is owned by LPR lanes x 4 channels covering all H*C channels, so a
+// lane's 4 channels lie in ONE head.  Each lane evaluates the softmax of its own head over the
+// row's <= ~13 in-edges itself (the per-edge scalars a_s[col_e,h] are same-address loads across the
+// head's lanes and come from L1/L2): the neighbour softmax needs no cross-lane traffic at all, and
+// the only shuffles are the head-mean in the epilogue (forward) and the C-channel dot products
+// (backward).  Constraints: C % 4 == 0, C/4 and H powers of two, H*C <= 256.
+#include <math.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr float kNegSlope = 0.2f;
+__device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : kNegSlope * x; }
+
+// a_s[r,h] = <h[r,h,:], att_src[h,:]>, a_d likewise.  rows = B*n flattened via (ld, bs).
+template <int LPR>
+__global__ __launch_bounds__(256) void gat_scores_kernel(const float* __restrict__ Hf, int64_t ldh, int64_t bsh,
+                                                         const float* __restrict__ att_s,
+                                                         const float* __restrict__ att_d, float* __restrict__ a_s,
+                                                         float* __restrict__ a_d, int32_t n, int32_t B, int32_t H,
+                                                         int32_t C) {
+  constexpr int RPW = 64 / LPR, RPB = RPW * 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  const int HC = H * C;
+  const int lph = C >> 2;  // lanes per head
+  const bool cact = c0 < HC;
+  float s0 = 0, s1 = 0, s2 = 0, s3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+  if (cact) {
+    s0 = att_s[c0]; s1 = att_s[c0 + 1]; s2 = att_s[c0 + 2]; s3 = att_s[c0 + 3];
+    d0 = att_d[c0]; d1 = att_d[c0 + 1]; d2 = att_d[c0 + 2]; d3 = att_d[c0 + 3];
+  }
+  const int64_t rows = (int64_t)B * n;
+  for (int64_t r = (int64_t)blockIdx.x * RPB + wave * RPW + sub; r < rows; r += (int64_t)gridDim.x * RPB) {
+    const int64_t b = r / n;
+    const int i = (int)(r - b * n);
+    float ps = 0.f, pd = 0.f;
+    if (cact) {
+      const float4 v = *reinterpret_cast<const float4*>(Hf + b * bsh + (int64_t)i * ldh + c0);
+      ps = v.x * s0 + v.y * s1 + v.z * s2 + v.w * s3;
+      pd = v.x * d0 + v.y * d1 + v.z * d2 + v.w * d3;
+    }
+    for (int off = lph >> 1; off > 0; off >>= 1) {
+      ps += __shfl_xor(ps, off, 64);
+      pd += __shfl_xor(pd, off, 64);
+    }
+    if (cact && (l % lph) == 0) {
+      const int h = c0 / C;
+      a_s[r * H + h] = ps;
+      a_d[r * H + h] = pd;
+    }
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ col, const float* __restrict__ Hf,
+                                                      int64_t ldh, int64_t bsh, const float* __restrict__ a_s,
+                                                      const float* __restrict__ a_d, const float* __restrict__ bias,
+                                                      float* __restrict__ alpha, float* __restrict__ Y, int64_t ldy,
+                                                      int64_t bsy, int32_t n, int64_t Ep, int32_t B, int32_t H,
+                                                      int32_t C, int32_t nRB, int32_t xcd_map) {
+  constexpr int RPW = 64 / LPR, RPB = RPW * 4;
+  const int bid = blockIdx.x;
+  int b, rb;
+  if (xcd_map) {
+    const int slot = bid >> 3;
+    b = (bid & 7) + 8 * (slot / nRB);
+    rb = slot % nRB;
+  } else {
+    b = bid / nRB;
+    rb = bid % nRB;
+  }
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  const int row = rb * RPB + wave * RPW + sub;
+  const int HC = H * C, lph = C >> 2;
+  const bool active = (row < n) && (c0 < HC);
+  const int h = active ? c0 / C : 0;
+  const float* __restrict__ Hb = Hf + (int64_t)b * bsh;
+  const float* __restrict__ as_b = a_s + (int64_t)b * n * H;
+  int start = 0, end = 0;
+  float ad = 0.f;
+  if (active) {
+    start = rowptr[row];
+    end = rowptr[row + 1];
+    ad = a_d[((int64_t)b * n + row) * H + h];
+  }
+  float m = -INFINITY;
+  for (int e = start; e < end; ++e) m = fmaxf(m, leaky(as_b[(int64_t)col[e] * H + h] + ad));
+  float den = 0.f;
+  for (int e = start; e < end; ++e) den += expf(leaky(as_b[(int64_t)col[e] * H + h] + ad) - m);
+  const float inv = 1.f / (den + 1e-16f);
+  float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  const bool leader = active && (l % lph) == 0;
+  for (int e = start; e < end; ++e) {
+    const int j = col[e];
+    const float al = expf(leaky(as_b[(int64_t)j * H + h] + ad) - m) * inv;
+    const float4 v = *reinterpret_cast<const float4*>(Hb + (int64_t)j * ldh + c0);
+    a0 += al * v.x; a1 += al * v.y; a2 += al * v.z; a3 += al * v.w;
+    if (leader && alpha) alpha[((int64_t)b * Ep + e) * H + h] = al;
+  }
+  // mean over heads: lanes holding the same channel of different heads are lph apart
+  for (int off = lph; off < lph * H; off <<= 1) {
+    a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64);
+    a2 += __shfl_xor(a2, off, 64); a3 += __shfl_xor(a3, off, 64);
+  }
+  if (active && h == 0) {
+    const float s = 1.f / (float)H;
+    float* yp = Y + (int64_t)b * bsy + (int64_t)row * ldy + c0;
+    float o0 = a0 * s, o1 = a1 * s, o2 = a2 * s, o3 = a3 * s;
+    if (bias) { o0 += bias[c0]; o1 += bias[c0 + 1]; o2 += bias[c0 + 2]; o3 += bias[c0 + 3]; }
+    if ((ldy & 3) == 0 && (bsy & 3) == 0 && ((uintptr_t)Y & 15) == 0) {
+      *reinterpret_cast<float4*>(yp) = make_float4(o0, o1, o2, o3);
+    } else {
+      yp[0] = o0; yp[1] = o1; yp[2] = o2; yp[3] = o3;
+    }
+  }
+}
+
+// Backward, destination side: per in-edge e of row i (head h)
+//   dalpha_e = <dy[i]/H, h[j_e,h,:]>, t = sum alpha_e dalpha_e, de_e = alpha_e (dalpha_e - t) * LeakyReLU'
+// writes de[b, slot, h] and da_d[b, i, h] = sum_e de_e.
+template <int LPR>
+__global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ col,
+                                                          const float* __restrict__ dY, int64_t lddy, int64_t bsdy,
+                                                          const float* __restrict__ Hf, int64_t ldh, int64_t bsh,
+                                                          const float* __restrict__ a_s, const float* __restrict__ a_d,
+                                                          const float* __restrict__ alpha, float* __restrict__ de,
+                                                          float* __restrict__ dad, int32_t n, int64_t Ep, int32_t B,
+                                                          int32_t H, int32_t C, int32_t nRB) {
+  constexpr int RPW = 64 / LPR, RPB = RPW * 4;
+  const int b = blockIdx.x / nRB, rb = blockIdx.x % nRB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  const int row = rb * RPB + wave * RPW + sub;
+  const int HC = H * C, lph = C >> 2;
+  const bool active = (row < n) && (c0 < HC);
+  const int h = active ? c0 / C : 0;
+  const int cc = c0 - h * C;  // channel inside the head = channel of dy
+  const float* __restrict__ Hb = Hf + (int64_t)b * bsh;
+  int start = 0, end = 0;
+  float g0 = 0, g1 = 0, g2 = 0, g3 = 0, ad = 0.f;
+  if (active) {
+    start = rowptr[row];
+    end = rowptr[row + 1];
+    const float* dp = dY + (int64_t)b * bsdy + (int64_t)row * lddy + cc;
+    const float s = 1.f / (float)H;
+    g0 = dp[0] * s; g1 = dp[1] * s; g2 = dp[2] * s; g3 = dp[3] * s;
+    ad = a_d[((int64_t)b * n + row) * H + h];
+  }
+  // the trip count must be uniform across the lanes that shuffle together (one row group): it is
+  float t = 0.f;
+  for (int e = start; e < end; ++e) {
+    const float4 v = *reinterpret_cast<const float4*>(Hb + (int64_t)col[e] * ldh + c0);
+    float d = g0 * v.x + g1 * v.y + g2 * v.z + g3 * v.w;
+    for (int off = lph >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+    t += alpha[((int64_t)b * Ep + e) * H + h] * d;
+  }
+  float sum_de = 0.f;
+  const bool leader = active && (l % lph) == 0;
+  for (int e = start; e < end; ++e) {
+    const int j = col[e];
+    const float4 v = *reinterpret_cast<const float4*>(Hb + (int64_t)j * ldh + c0);
+    float d = g0 * v.x + g1 * v.y + g2 * v.z + g3 * v.w;
+    for (int off = lph >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+    const float al = alpha[((int64_t)b * Ep + e) * H + h];
+    const float pre = a_s[((int64_t)b * n + j) * H + h] + ad;
+    const float dev = al * (d - t) * (pre > 0.f ? 1.f : kNegSlope);
+    sum_de += dev;
+    if (leader) de[((int64_t)b * Ep + e) * H + h] = dev;
+  }
+  if (leader) dad[((int64_t)b * n + row) * H + h] = sum_de;
+}
+
+// Backward, source side (transposed CSR): for source row j, head h
+//   da_s[j] = sum_{e: src=j} de_e
+//   dh[j,h,:] = sum_{e: src=j} alpha_e dy[dst_e]/H + da_s[j] att_src[h,:] + da_d[j] att_dst[h,:]
+template <int LPR>
+__global__ __launch_bounds__(256) void gat_bwd_src_kernel(const int32_t* __restrict__ trowptr,
+                                                          const int32_t* __restrict__ tcol,
+                                                          const int32_t* __restrict__ tslot,
+                                                          const float* __restrict__ dY, int64_t lddy, int64_t bsdy,
+                                                          const float* __restrict__ alpha, const float* __restrict__ de,
+                                                          const float* __restrict__ dad, const float* __restrict__ att_s,
+                                                          const float* __restrict__ att_d, float* __restrict__ das,
+                                                          float* __restrict__ dH, int64_t lddh, int64_t bsdh,
+                                                          int32_t n, int64_t Ep, int32_t B, int32_t H, int32_t C,
+                                                          int32_t nRB) {
+  constexpr int RPW = 64 / LPR, RPB = RPW * 4;
+  const int b = blockIdx.x / nRB, rb = blockIdx.x % nRB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  const int row = rb * RPB + wave * RPW + sub;
+  const int HC = H * C, lph = C >> 2;
+  if (!(row < n) || !(c0 < HC)) return;
+  const int h = c0 / C, cc = c0 - h * C;
+  const float s = 1.f / (float)H;
+  const int start = trowptr[row], end = trowptr[row + 1];
+  float a0 = 0, a1 = 0, a2 = 0, a3 = 0, sde = 0.f;
+  for (int e = start; e < end; ++e) {
+    const int i = tcol[e];
+    const int64_t sl = ((int64_t)b * Ep + tslot[e]) * H + h;
+    const float al = alpha[sl] * s;
+    sde += de[sl];
+    const float* dp = dY + (int64_t)b * bsdy + (int64_t)i * lddy + cc;
+    a0 += al * dp[0]; a1 += al * dp[1]; a2 += al * dp[2]; a3 += al * dp[3];
+  }
+  const float dd = dad[((int64_t)b * n + row) * H + h];
+  a0 += sde * att_s[c0] + dd * att_d[c0];
+  a1 += sde * att_s[c0 + 1] + dd * att_d[c0 + 1];
+  a2 += sde * att_s[c0 + 2] + dd * att_d[c0 + 2];
+  a3 += sde * att_s[c0 + 3] + dd * att_d[c0 + 3];
+  float* o = dH + (int64_t)b * bsdh + (int64_t)row * lddh + c0;
+  o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+  if ((l % lph) == 0) das[((int64_t)b * n + row) * H + h] = sde;
+}
+
+// part[block][2][HC]: sum_rows da_s[r,h] * h[r,hc]  |  sum_rows da_d[r,h] * h[r,hc]
+template <int LPR>
+__global__ __launch_bounds__(256) void gat_datt_kernel(const float* __restrict__ Hf, int64_t ldh, int64_t bsh,
+                                                       const float* __restrict__ das, const float* __restrict__ dad,
+                                                       float* __restrict__ part, int32_t n, int32_t B, int32_t H,
+                                                       int32_t C) {
+  constexpr int RPW = 64 / LPR, RPB = RPW * 4;
+  __shared__ float red[RPB][LPR * 4 * 2 + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  const int HC = H * C;
+  const bool cact = c0 < HC;
+  const int h = cact ? c0 / C : 0;
+  float s0 = 0, s1 = 0, s2 = 0, s3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+  const int64_t rows = (int64_t)B * n;
+  if (cact)
+    for (int64_t r = (int64_t)blockIdx.x * RPB + wave * RPW + sub; r < rows; r += (int64_t)gridDim.x * RPB) {
+      const int64_t b = r / n;
+      const int i = (int)(r - b * n);
+      const float4 v = *reinterpret_cast<const float4*>(Hf + b * bsh + (int64_t)i * ldh + c0);
+      const float ws = das[r * H + h], wd = dad[r * H + h];
+      s0 += ws * v.x; s1 += ws * v.y; s2 += ws * v.z; s3 += ws * v.w;
+      d0 += wd * v.x; d1 += wd * v.y; d2 += wd * v.z; d3 += wd * v.w;
+    }
+  float* r_ = red[wave * RPW + sub];
+  r_[c0] = s0; r_[c0 + 1] = s1; r_[c0 + 2] = s2; r_[c0 + 3] = s3;
+  r_[LPR * 4 + c0] = d0; r_[LPR * 4 + c0 + 1] = d1; r_[LPR * 4 + c0 + 2] = d2; r_[LPR * 4 + c0 + 3] = d3;
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * LPR * 4; idx += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < RPB; ++q) s += red[q][idx];
+    const int which = idx / (LPR * 4), c = idx % (LPR * 4);
+    if (c < HC) part[((size_t)blockIdx.x * 2 + which) * HC + c] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int32_t nparts,
+                                                           int32_t pstride, float* __restrict__ out, int32_t count,
+                                                           int32_t accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= count) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * pstride + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+__global__ __launch_bounds__(256) void alpha_reorder_kernel(const int32_t* __restrict__ eperm,
+                                                            const float* __restrict__ a_slots,
+                                                            float* __restrict__ a_edges, int64_t Ep, int32_t H) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Ep * H) return;
+  const int64_t s = idx / H;
+  const int k = (int)(idx - s * H);
+  a_edges[(int64_t)eperm[s] * H + k] = a_slots[idx];
+}
+
+// keep-mask as one 64-bit ballot word per wave of edges
+__global__ __launch_bounds__(256) void prune_ballot_kernel(const float* __restrict__ a_edges, float thr, int64_t Ep,
+                                                           unsigned long long* __restrict__ words) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool keep = idx < Ep && a_edges[idx] >= thr;
+  const unsigned long long m = __ballot(keep);
+  if ((threadIdx.x & 63) == 0 && (idx >> 6) < (Ep + 63) / 64) words[idx >> 6] = m;
+}
+
+constexpr int kGatBlocks = 512;
+
+int gat_check(const gcl_graph_t* g, int32_t H, int32_t C, int* lpr) {
+  GCL_CHECK_ARG(g, "gat: null graph");
+  GCL_CHECK_ARG(H >= 1 && C >= 4 && (C % 4) == 0, "gat: C must be a positive multiple of 4 (H=%d C=%d)", H, C);
+  const int lph = C / 4;
+  if ((lph & (lph - 1)) != 0 || (H & (H - 1)) != 0 || H * C > 256) {
+    gcl::set_error("gat: unsupported head geometry H=%d C=%d (need C/4 and H powers of two, H*C <= 256)", H, C);
+    return GCL_EUNSUPPORTED;
+  }
+  const int lanes = H * lph;
+  *lpr = lanes <= 4 ? 4 : lanes <= 8 ? 8 : lanes <= 16 ? 16 : lanes <= 32 ? 32 : 64;
+  return GCL_OK;
+}
+
+}  // namespace
+
+#define GCL_DISPATCH_LPR(lpr, CALL) \
+  switch (lpr) {                    \
+    case 4: CALL(4); break;         \
+    case 8: CALL(8); break;         \
+    case 16: CALL(16); break;       \
+    case 32: CALL(32); break;       \
+    default: CALL(64); break;       \
+  }
+
+extern "C" int gcl_gat_fwd(const gcl_graph_t* g, const float* h, int64_t ldh, int64_t bsh, const float* att_src,
+                           const float* att_dst, const float* bias, float* a_src, float* a_dst, float* alpha,
+                           float* y, int64_t ldy, int64_t bsy, int32_t B, int32_t H, int32_t C, gcl_stream_t stream) {
+  int lpr = 0;
+  int rc = gat_check(g, H, C, &lpr);
+  if (rc) return rc;
+  GCL_CHECK_ARG(h && att_src && att_dst && a_src && a_dst && y, "gat_fwd: null argument");
+  GCL_CHECK_ARG(B > 0 && ldh >= H * C && ldy >= C, "gat_fwd: bad shape");
+  GCL_CHECK_ARG((ldh % 4) == 0 && (bsh % 4) == 0 && gcl::aligned16(h), "gat_fwd: h must be 16-B aligned with ld %% 4 == 0");
+  GCL_CHECK_ARG(g->kind == GCL_GRAPH_GAT, "gat_fwd: graph was not created with GCL_GRAPH_GAT");
+  hipStream_t st = (hipStream_t)stream;
+  const int rpb = (64 / lpr) * 4;
+  const int64_t rows = (int64_t)B * g->n;
+  int64_t nbs = gcl::cdiv(rows, rpb);
+  if (nbs > 4096) nbs = 4096;
+#define CALL(L)                                                                                                    \
+  hipLaunchKernelGGL((gat_scores_kernel<L>), dim3((unsigned)nbs), dim3(256), 0, st, h, ldh, bsh, att_src, att_dst, \
+                     a_src, a_dst, g->n, B, H, C)
+  GCL_DISPATCH_LPR(lpr, CALL)
+#undef CALL
+  GCL_CHECK_LAUNCH();
+  const int32_t nRB = (int32_t)gcl::cdiv(g->n, rpb);
+  const int xcd_map = B >= 8 ? 1 : 0;
+  const int64_t nb = xcd_map ? (int64_t)8 * gcl::cdiv(B, 8) * nRB : (int64_t)B * nRB;
+#define CALL(L)                                                                                                       \
+  hipLaunchKernelGGL((gat_fwd_kernel<L>), dim3((unsigned)nb), dim3(256), 0, st, g->rowptr, g->col, h, ldh, bsh, a_src, \
+                     a_dst, bias, alpha, y, ldy, bsy, g->n, g->e, B, H, C, nRB, xcd_map)
+  GCL_DISPATCH_LPR(lpr, CALL)
+#undef CALL
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+extern "C" size_t gcl_gat_bwd_ws_bytes(int64_t e_prime, int32_t n, int32_t B, int32_t H, int32_t C) {
+  const size_t de = (size_t)B * e_prime * H;
+  const size_t nodes = (size_t)B * n * H * 2;  // da_d, da_s
+  const size_t parts = (size_t)kGatBlocks * 2 * H * C + (size_t)1024 * C;
+  return (de + nodes + parts) * sizeof(float) + 256;
+}
+
+extern "C" int gcl_colsum(const float*, int64_t, int64_t, int32_t, float*, int32_t, void*, size_t, gcl_stream_t);
+extern "C" size_t gcl_colsum_ws_bytes(int64_t, int32_t);
+
+extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, int64_t bsdy, const float* h,
+                           int64_t ldh, int64_t bsh, const float* att_src, const float* att_dst, const float* a_src,
+                           const float* a_dst, const float* alpha, float* dh, int64_t lddh, int64_t bsdh,
+                           float* d_att_src, float* d_att_dst, float* d_bias, int32_t accumulate, int32_t B, int32_t H,
+                           int32_t C, void* ws, size_t ws_bytes, gcl_stream_t stream) {
+  int lpr = 0;
+  int rc = gat_check(g, H, C, &lpr);
+  if (rc) return rc;
+  GCL_CHECK_ARG(dy && h && att_src && att_dst && a_src && a_dst && alpha && dh && d_att_src && d_att_dst,
+                "gat_bwd: null argument");
+  GCL_CHECK_ARG(B > 0 && ldh >= H * C && lddh >= H * C && lddy >= C, "gat_bwd: bad shape");
+  GCL_CHECK_ARG((ldh % 4) == 0 && (bsh % 4) == 0 && gcl::aligned16(h), "gat_bwd: h must be 16-B aligned with ld %% 4 == 0");
+  GCL_CHECK_ARG(g->kind == GCL_GRAPH_GAT, "gat_bwd: graph was not created with GCL_GRAPH_GAT");
+  GCL_CHECK_ARG(bsdy == (int64_t)g->n * lddy || B == 1, "gat_bwd: dy must be row-contiguous across the batch");
+  GCL_CHECK_ARG(ws && ws_bytes >= gcl_gat_bwd_ws_bytes(g->e, g->n, B, H, C), "gat_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* de = (float*)ws;
+  float* dad = de + (size_t)B * g->e * H;
+  float* das = dad + (size_t)B * g->n * H;
+  float* part = das + (size_t)B * g->n * H;
+  float* cs_ws = part + (size_t)kGatBlocks * 2 * H * C;
+  const int rpb = (64 / lpr) * 4;
+  const int32_t nRB = (int32_t)gcl::cdiv(g->n, rpb);
+  const unsigned nb = (unsigned)((int64_t)B * nRB);
+#define CALL(L)                                                                                                    \
+  hipLaunchKernelGGL((gat_bwd_dst_kernel<L>), dim3(nb), dim3(256), 0, st, g->rowptr, g->col, dy, lddy, bsdy, h, ldh, \
+                     bsh, a_src, a_dst, alpha, de, dad, g->n, g->e, B, H, C, nRB)
+  GCL_DISPATCH_LPR(lpr, CALL)
+#undef CALL
+  GCL_CHECK_LAUNCH();
+#define CALL(L)                                                                                                       \
+  hipLaunchKernelGGL((gat_bwd_src_kernel<L>), dim3(nb), dim3(256), 0, st, g->trowptr, g->tcol, g->tslot, dy, lddy,    \
+                     bsdy, alpha, de, dad, att_src, att_dst, das, dh, lddh, bsdh, g->n, g->e, B, H, C, nRB)
+  GCL_DISPATCH_LPR(lpr, CALL)
+#undef CALL
+  GCL_CHECK_LAUNCH();
+  const int64_t rows = (int64_t)B * g->n;
+  int64_t nbd = gcl::cdiv(rows, rpb);
+  if (nbd > kGatBlocks) nbd = kGatBlocks;
+#define CALL(L)                                                                                                 \
+  hipLaunchKernelGGL((gat_datt_kernel<L>), dim3((unsigned)nbd), dim3(256), 0, st, h, ldh, bsh, das, dad, part, g->n, \
+                     B, H, C)
+  GCL_DISPATCH_LPR(lpr, CALL)
+#undef CALL
+  GCL_CHECK_LAUNCH();
+  const int HC = H * C;
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)gcl::cdiv(HC, 256)), dim3(256), 0, st, part, (int)nbd, 2 * HC,
+                     d_att_src, HC, accumulate);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)gcl::cdiv(HC, 256)), dim3(256), 0, st, part + HC, (int)nbd,
+                     2 * HC, d_att_dst, HC, accumulate);
+  GCL_CHECK_LAUNCH();
+  if (d_bias) {
+    // dy rows are contiguous across the batch (checked above): one flat column sum
+    rc = gcl_colsum(dy, lddy, rows, C, d_bias, accumulate, cs_ws, gcl_colsum_ws_bytes(rows, C), stream);
+    if (rc) return rc;
+  }
+  return GCL_OK;
+}
+
+extern "C" int gcl_gat_alpha_to_edge_order(const gcl_graph_t* g, const float* alpha_slots, float* alpha_edges,
+                                           int32_t H, gcl_stream_t stream) {
+  GCL_CHECK_ARG(g && alpha_slots && alpha_edges && H >= 1, "gat_alpha_to_edge_order: bad argument");
+  const int64_t total = g->e * H;
+  hipLaunchKernelGGL(alpha_reorder_kernel, dim3((unsigned)gcl::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     g->eperm, alpha_slots, alpha_edges, g->e, H);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+extern "C" size_t gcl_gat_prune_ws_bytes(int64_t e_prime) { return (size_t)((e_prime + 63) / 64 + 1) * 8; }
+
+extern "C" int gcl_gat_prune(const gcl_graph_t* g, const float* alpha_edges, float threshold, int64_t* edge_index_out,
+                             int64_t* kept, void* ws, size_t ws_bytes, gcl_stream_t stream) {
+  GCL_CHECK_ARG(g && alpha_edges && edge_index_out && kept, "gat_prune: null argument");
+  GCL_CHECK_ARG(ws && ws_bytes >= gcl_gat_prune_ws_bytes(g->e), "gat_prune: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t Ep = g->e, nw = (Ep + 63) / 64;
+  hipLaunchKernelGGL(prune_ballot_kernel, dim3((unsigned)gcl::cdiv(nw * 64, 256)), dim3(256), 0, st, alpha_edges,
+                     threshold, Ep, (unsigned long long*)ws);
+  GCL_CHECK_LAUNCH();
+  std::vector<unsigned long long> words((size_t)nw);
+  GCL_CHECK_HIP(hipMemcpyAsync(words.data(), ws, (size_t)nw * 8, hipMemcpyDeviceToHost, st));
+  GCL_CHECK_HIP(hipStreamSynchronize(st));
+  // prefix compaction of the ballot words in PyG edge order
+  int64_t k = 0;
+  for (int64_t wi = 0; wi < nw; ++wi) k += __builtin_popcountll(words[(size_t)wi]);
+  int64_t o = 0;
+  for (int64_t e = 0; e < Ep; ++e)
+    if ((words[(size_t)(e >> 6)] >> (e & 63)) & 1ull) {
+      edge_index_out[o] = g->h_edges[e];
+      edge_index_out[k + o] = g->h_edges[Ep + e];
+      ++o;
+    }
+  *kept = k;
+  return GCL_OK;
+}

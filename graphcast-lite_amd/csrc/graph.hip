@@ -1,0 +1,197 @@
+// Graph handle: reference edge list -> receiver-sorted CSR + sender-sorted transpose.
+// Host-side counting sorts; one-time setup.  See include/gcl.h for the contract.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace gcl {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace gcl
+
+extern "C" int gcl_version(void) { return GCL_VERSION; }
+extern "C" const char* gcl_last_error(void) { return gcl::g_err; }
+
+static int check_edges(const int64_t* ei, int64_t E, int32_t n, int32_t kind) {
+  GCL_CHECK_ARG(n > 0, "graph: n must be positive (got %d)", n);
+  GCL_CHECK_ARG(E >= 0, "graph: negative edge count");
+  GCL_CHECK_ARG(E == 0 || ei != nullptr, "graph: null edge_index");
+  GCL_CHECK_ARG(kind >= GCL_GRAPH_GCN && kind <= GCL_GRAPH_MEAN, "graph: unknown kind %d", kind);
+  for (int64_t e = 0; e < 2 * E; ++e)
+    GCL_CHECK_ARG(ei[e] >= 0 && ei[e] < n, "graph: node index %lld out of range [0,%d)", (long long)ei[e], n);
+  return GCL_OK;
+}
+
+extern "C" int gcl_graph_count_edges(const int64_t* ei, int64_t E, int32_t n, int32_t kind, int64_t* e_out) {
+  int rc = check_edges(ei, E, n, kind);
+  if (rc) return rc;
+  GCL_CHECK_ARG(e_out, "graph: null e_out");
+  if (kind == GCL_GRAPH_MEAN) {
+    *e_out = E;
+    return GCL_OK;
+  }
+  int64_t kept = 0;
+  for (int64_t e = 0; e < E; ++e) kept += (ei[e] != ei[E + e]);
+  *e_out = kept + n;
+  GCL_CHECK_ARG(*e_out < (int64_t)INT32_MAX, "graph: too many edges for int32 CSR");
+  return GCL_OK;
+}
+
+// Edge list in PyG order: kept edges in input order, then loops 0..n-1 (GCN/GAT kinds).
+static void pyg_order(const int64_t* ei, int64_t E, int32_t n, int32_t kind, std::vector<int64_t>& s,
+                      std::vector<int64_t>& r) {
+  s.clear();
+  r.clear();
+  for (int64_t e = 0; e < E; ++e) {
+    if (kind != GCL_GRAPH_MEAN && ei[e] == ei[E + e]) continue;
+    s.push_back(ei[e]);
+    r.push_back(ei[E + e]);
+  }
+  if (kind != GCL_GRAPH_MEAN)
+    for (int32_t i = 0; i < n; ++i) {
+      s.push_back(i);
+      r.push_back(i);
+    }
+}
+
+extern "C" int gcl_graph_build_host(const int64_t* ei, int64_t E, int32_t n, int32_t kind, int32_t* rowptr,
+                                    int32_t* col, float* w, int32_t* eperm, int32_t* trowptr, int32_t* tcol,
+                                    float* tw, int32_t* tslot) {
+  int rc = check_edges(ei, E, n, kind);
+  if (rc) return rc;
+  GCL_CHECK_ARG(rowptr && col && w && eperm && trowptr && tcol && tw && tslot, "graph: null output array");
+  std::vector<int64_t> s, r;
+  pyg_order(ei, E, n, kind, s, r);
+  const int64_t Ep = (int64_t)s.size();
+
+  std::vector<int32_t> indeg(n, 0);
+  for (int64_t e = 0; e < Ep; ++e) indeg[r[e]]++;
+
+  // Edge weights in fp32, the way PyG forms them: deg^-1/2 per node, then dis[row]*dis[col].
+  std::vector<float> node_scale(n, 1.f);
+  if (kind == GCL_GRAPH_GCN) {
+    for (int32_t i = 0; i < n; ++i) node_scale[i] = indeg[i] > 0 ? 1.0f / sqrtf((float)indeg[i]) : 0.f;  // torch CPU pow(-0.5) == 1/sqrt
+  } else if (kind == GCL_GRAPH_MEAN) {
+    for (int32_t i = 0; i < n; ++i) node_scale[i] = 1.f / (float)(indeg[i] > 1 ? indeg[i] : 1);
+  }
+  auto edge_w = [&](int64_t e) -> float {
+    if (kind == GCL_GRAPH_GCN) return node_scale[s[e]] * node_scale[r[e]];
+    if (kind == GCL_GRAPH_MEAN) return node_scale[r[e]];
+    return 1.f;
+  };
+
+  // forward CSR: stable counting sort by receiver
+  rowptr[0] = 0;
+  for (int32_t i = 0; i < n; ++i) rowptr[i + 1] = rowptr[i] + indeg[i];
+  std::vector<int32_t> cur(rowptr, rowptr + n);
+  std::vector<int32_t> slot_of(Ep);
+  for (int64_t e = 0; e < Ep; ++e) {
+    int32_t p = cur[r[e]]++;
+    col[p] = (int32_t)s[e];
+    w[p] = edge_w(e);
+    eperm[p] = (int32_t)e;
+    slot_of[e] = p;
+  }
+  // transpose: stable counting sort by sender
+  std::vector<int32_t> outdeg(n, 0);
+  for (int64_t e = 0; e < Ep; ++e) outdeg[s[e]]++;
+  trowptr[0] = 0;
+  for (int32_t i = 0; i < n; ++i) trowptr[i + 1] = trowptr[i] + outdeg[i];
+  std::vector<int32_t> tcur(trowptr, trowptr + n);
+  for (int64_t e = 0; e < Ep; ++e) {
+    int32_t p = tcur[s[e]]++;
+    tcol[p] = (int32_t)r[e];
+    tw[p] = edge_w(e);
+    tslot[p] = slot_of[e];
+  }
+  return GCL_OK;
+}
+
+template <typename T>
+static int upload(T** dst, const T* src, size_t count) {
+  *dst = nullptr;
+  if (count == 0) count = 1;
+  hipError_t e = hipMalloc((void**)dst, count * sizeof(T));
+  if (e != hipSuccess) {
+    gcl::set_error("graph_create: hipMalloc(%zu) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    return GCL_ENOMEM;
+  }
+  GCL_CHECK_HIP(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+  return GCL_OK;
+}
+
+extern "C" void gcl_graph_destroy(gcl_graph_t* g) {
+  if (!g) return;
+  void* ptrs[] = {g->rowptr, g->col, g->eperm, g->trowptr, g->tcol, g->tslot, g->w, g->tw};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  free(g->h_edges);
+  delete g;
+}
+
+extern "C" int gcl_graph_create(const int64_t* ei, int64_t E, int32_t n, int32_t kind, gcl_graph_t** out) {
+  GCL_CHECK_ARG(out, "graph_create: null out");
+  *out = nullptr;
+  int64_t Ep = 0;
+  int rc = gcl_graph_count_edges(ei, E, n, kind, &Ep);
+  if (rc) return rc;
+  std::vector<int32_t> rowptr(n + 1), col(Ep + 1), eperm(Ep + 1), trowptr(n + 1), tcol(Ep + 1), tslot(Ep + 1);
+  std::vector<float> w(Ep + 1), tw(Ep + 1);
+  rc = gcl_graph_build_host(ei, E, n, kind, rowptr.data(), col.data(), w.data(), eperm.data(), trowptr.data(),
+                            tcol.data(), tw.data(), tslot.data());
+  if (rc) return rc;
+  gcl_graph_t* g = new gcl_graph_t();
+  g->n = n;
+  g->e = Ep;
+  g->kind = kind;
+  for (int32_t i = 0; i < n; ++i) {
+    int32_t d = rowptr[i + 1] - rowptr[i], t = trowptr[i + 1] - trowptr[i];
+    if (d > g->max_in_deg) g->max_in_deg = d;
+    if (t > g->max_out_deg) g->max_out_deg = t;
+  }
+  std::vector<int64_t> s, r;
+  pyg_order(ei, E, n, kind, s, r);
+  g->h_edges = (int64_t*)malloc(sizeof(int64_t) * 2 * (Ep > 0 ? Ep : 1));
+  if (!g->h_edges) {
+    delete g;
+    gcl::set_error("graph_create: host allocation failed");
+    return GCL_ENOMEM;
+  }
+  if (Ep) {
+    memcpy(g->h_edges, s.data(), sizeof(int64_t) * Ep);
+    memcpy(g->h_edges + Ep, r.data(), sizeof(int64_t) * Ep);
+  }
+  rc = upload(&g->rowptr, rowptr.data(), n + 1);
+  if (!rc) rc = upload(&g->col, col.data(), Ep);
+  if (!rc) rc = upload(&g->w, w.data(), Ep);
+  if (!rc) rc = upload(&g->eperm, eperm.data(), Ep);
+  if (!rc) rc = upload(&g->trowptr, trowptr.data(), n + 1);
+  if (!rc) rc = upload(&g->tcol, tcol.data(), Ep);
+  if (!rc) rc = upload(&g->tw, tw.data(), Ep);
+  if (!rc) rc = upload(&g->tslot, tslot.data(), Ep);
+  if (rc) {
+    gcl_graph_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return GCL_OK;
+}
+
+extern "C" int32_t gcl_graph_num_nodes(const gcl_graph_t* g) { return g ? g->n : 0; }
+extern "C" int64_t gcl_graph_num_edges(const gcl_graph_t* g) { return g ? g->e : 0; }
+extern "C" int32_t gcl_graph_max_in_degree(const gcl_graph_t* g) { return g ? g->max_in_deg : 0; }
+extern "C" const int32_t* gcl_graph_eperm_device(const gcl_graph_t* g) { return g ? g->eperm : nullptr; }
+extern "C" int gcl_graph_export_edges(const gcl_graph_t* g, int64_t* out) {
+  GCL_CHECK_ARG(g && out, "graph_export_edges: null argument");
+  memcpy(out, g->h_edges, sizeof(int64_t) * 2 * g->e);
+  return GCL_OK;
+}

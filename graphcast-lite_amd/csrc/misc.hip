@@ -1,0 +1,183 @@
+// Input assembly, loss (+gradient), Adam and strided row copies: the elementwise ends of the path.
+#include "common.h"
+
+namespace {
+
+// out[b, i, :] = i < G ? [x[b,i,:Cdyn] | gstat[i,:Cs]] : [0 | mstat[i-G,:Cs]]
+// (src/models.py:776-806; the reference allocates the zero block and concatenates 3x per forward)
+__global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__ x, const float* __restrict__ gs,
+                                                       const float* __restrict__ ms, float* __restrict__ out,
+                                                       int64_t ldo, int32_t B, int32_t G, int32_t M, int32_t Cdyn,
+                                                       int32_t Cs) {
+  const int C = Cdyn + Cs;
+  const int64_t total = (int64_t)B * (G + M) * C;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const int64_t bi = idx / C;
+    const int i = (int)(bi % (G + M));
+    const int64_t b = bi / (G + M);
+    float v;
+    if (i < G)
+      v = c < Cdyn ? x[(b * G + i) * Cdyn + c] : gs[(int64_t)i * Cs + (c - Cdyn)];
+    else
+      v = c < Cdyn ? 0.f : ms[(int64_t)(i - G) * Cs + (c - Cdyn)];
+    out[bi * ldo + c] = v;
+  }
+}
+
+// loss partials + gradient (src/train.py:203-213,85-102)
+__global__ __launch_bounds__(256) void wmse_kernel(const float* __restrict__ delta, int64_t ldd, int64_t bsd,
+                                                   const float* __restrict__ xl, int64_t ldx, int64_t bsx,
+                                                   const float* __restrict__ y, int64_t ldy, int64_t bsy,
+                                                   const float* __restrict__ node_w, const float* __restrict__ chan_w,
+                                                   float inv_wsum, float grad_scale, float* __restrict__ dd,
+                                                   float* __restrict__ out_state, float* __restrict__ part,
+                                                   int32_t B, int32_t G, int32_t C) {
+  __shared__ float red[4];
+  const int64_t total = (int64_t)B * G * C;
+  float acc = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const int64_t bg = idx / C;
+    const int g = (int)(bg % G);
+    const int64_t b = bg / G;
+    float o = delta[b * bsd + (int64_t)g * ldd + c];
+    if (xl) o += xl[b * bsx + (int64_t)g * ldx + c];
+    const float t = y[b * bsy + (int64_t)g * ldy + c];
+    float w = 1.f;
+    if (chan_w) w *= chan_w[c];
+    if (node_w) w *= node_w[g];
+    const float d = o - t;
+    acc += (d * d) * w;
+    if (dd) dd[idx] = 2.f * w * d * inv_wsum * grad_scale;
+    if (out_state) out_state[idx] = o;
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void wmse_final_kernel(const float* __restrict__ part, int32_t nparts, float inv_wsum,
+                                  float* __restrict__ loss) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int p = threadIdx.x; p < nparts; p += 256) s += (double)part[p];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *loss = (float)((red[0] + red[1] + red[2] + red[3]) * (double)inv_wsum);
+}
+
+// torch.optim.Adam (no amsgrad, no maximize): src/main.py:212
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t count,
+                                                   float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                   float bc2_sqrt, float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    float gi = g[i] * gscale;
+    if (wd != 0.f) gi += wd * p[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, int64_t lds, int64_t bss,
+                                                        float* __restrict__ dst, int64_t ldd, int64_t bsd, int32_t B,
+                                                        int32_t rows, int32_t F, int32_t vec) {
+  if (vec) {
+    const int nv = F >> 2;
+    const int64_t total = (int64_t)B * rows * nv;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+      const int c = (int)(idx % nv) * 4;
+      const int64_t br = idx / nv;
+      const int r = (int)(br % rows);
+      const int64_t b = br / rows;
+      *reinterpret_cast<float4*>(dst + b * bsd + (int64_t)r * ldd + c) =
+          *reinterpret_cast<const float4*>(src + b * bss + (int64_t)r * lds + c);
+    }
+  } else {
+    const int64_t total = (int64_t)B * rows * F;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+      const int c = (int)(idx % F);
+      const int64_t br = idx / F;
+      const int r = (int)(br % rows);
+      const int64_t b = br / rows;
+      dst[b * bsd + (int64_t)r * ldd + c] = src[b * bss + (int64_t)r * lds + c];
+    }
+  }
+}
+
+inline unsigned grid_for(int64_t total, int cap = 4096) {
+  int64_t nb = gcl::cdiv(total > 0 ? total : 1, 256);
+  return (unsigned)(nb > cap ? cap : nb);
+}
+constexpr int kLossBlocks = 1024;
+
+}  // namespace
+
+extern "C" int gcl_assemble_input(const float* x, const float* gs, const float* ms, float* out, int64_t ldo,
+                                  int32_t B, int32_t G, int32_t M, int32_t Cdyn, int32_t Cs, gcl_stream_t stream) {
+  GCL_CHECK_ARG(x && gs && ms && out, "assemble_input: null argument");
+  GCL_CHECK_ARG(B > 0 && G > 0 && M >= 0 && Cdyn >= 0 && Cs >= 0 && ldo >= Cdyn + Cs, "assemble_input: bad shape");
+  const int64_t total = (int64_t)B * (G + M) * (Cdyn + Cs);
+  hipLaunchKernelGGL(assemble_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, x, gs, ms, out,
+                     ldo, B, G, M, Cdyn, Cs);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+extern "C" size_t gcl_wmse_ws_bytes(int32_t B, int32_t G, int32_t C) {
+  (void)B; (void)G; (void)C;
+  return (size_t)kLossBlocks * sizeof(float);
+}
+
+extern "C" int gcl_wmse_fwd_bwd(const float* delta, int64_t ldd, int64_t bsd, const float* x_last, int64_t ldx,
+                                int64_t bsx, const float* y, int64_t ldy, int64_t bsy, const float* node_w,
+                                const float* chan_w, float inv_wsum, float grad_scale, float* d_delta,
+                                float* out_state, float* loss_out, int32_t B, int32_t G, int32_t C, void* ws,
+                                size_t ws_bytes, gcl_stream_t stream) {
+  GCL_CHECK_ARG(delta && y && loss_out, "wmse: null argument");
+  GCL_CHECK_ARG(B > 0 && G > 0 && C > 0 && ldd >= C && ldy >= C && (!x_last || ldx >= C), "wmse: bad shape");
+  GCL_CHECK_ARG(ws && ws_bytes >= gcl_wmse_ws_bytes(B, G, C), "wmse: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)B * G * C;
+  const unsigned nb = grid_for(total, kLossBlocks);
+  hipLaunchKernelGGL(wmse_kernel, dim3(nb), dim3(256), 0, st, delta, ldd, bsd, x_last, ldx, bsx, y, ldy, bsy, node_w,
+                     chan_w, inv_wsum, grad_scale, d_delta, out_state, (float*)ws, B, G, C);
+  hipLaunchKernelGGL(wmse_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, (int)nb, inv_wsum, loss_out);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+extern "C" int gcl_adam_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
+                             gcl_stream_t stream) {
+  GCL_CHECK_ARG(p && g && m && v, "adam: null argument");
+  GCL_CHECK_ARG(count >= 0 && step >= 1, "adam: bad count/step");
+  if (count == 0) return GCL_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, count,
+                     lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+extern "C" int gcl_copy_rows(const float* src, int64_t lds, int64_t bss, float* dst, int64_t ldd, int64_t bsd,
+                             int32_t B, int32_t rows, int32_t F, gcl_stream_t stream) {
+  GCL_CHECK_ARG(src && dst, "copy_rows: null argument");
+  GCL_CHECK_ARG(B > 0 && rows >= 0 && F > 0 && lds >= F && ldd >= F, "copy_rows: bad shape");
+  if (rows == 0) return GCL_OK;
+  const int vec = (F % 4 == 0) && (lds % 4 == 0) && (ldd % 4 == 0) && (bss % 4 == 0) && (bsd % 4 == 0) &&
+                  gcl::aligned16(src) && gcl::aligned16(dst);
+  const int64_t total = (int64_t)B * rows * (vec ? F / 4 : F);
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, src, lds, bss,
+                     dst, ldd, bsd, B, rows, F, vec);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}

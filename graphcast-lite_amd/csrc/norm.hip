@@ -1,0 +1,262 @@
+// PyG LayerNorm (mode="node" / mode="graph") forward + backward, and column sums.
+// Reference: src/models.py:102-104,368-374 (construction), :108,:421 (application); arithmetic per
+// SURVEY.md Appendix A.4.  Row-wise kernels use the same row->lane-group mapping as the
+// aggregation kernel (LPR lanes x 4 channels, 16-B accesses, shuffle reductions inside the group).
+#include "common.h"
+
+namespace {
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ void load4(const float* p, int c0, int F, bool vec, float& a, float& b, float& c, float& d) {
+  if (vec) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    a = v.x; b = v.y; c = v.z; d = v.w;
+  } else {
+    a = (c0 < F) ? p[0] : 0.f;
+    b = (c0 + 1 < F) ? p[1] : 0.f;
+    c = (c0 + 2 < F) ? p[2] : 0.f;
+    d = (c0 + 3 < F) ? p[3] : 0.f;
+  }
+}
+__device__ __forceinline__ void store4(float* p, int c0, int F, bool vec, float a, float b, float c, float d) {
+  if (vec) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+  } else {
+    if (c0 < F) p[0] = a;
+    if (c0 + 1 < F) p[1] = b;
+    if (c0 + 2 < F) p[2] = c;
+    if (c0 + 3 < F) p[3] = d;
+  }
+}
+
+// y = (x - mean) * rstd * gamma + beta ; stats[row] = (mean, rstd)
+template <int LPR>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ X, int64_t ldx,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, float* __restrict__ Y, int64_t ldy,
+                                                     float* __restrict__ stats, int64_t rows, int32_t F, int32_t vx,
+                                                     int32_t vy) {
+  constexpr int RPB = (64 / LPR) * 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  const float invF = 1.f / (float)F;
+  float g0 = 0, g1 = 0, g2 = 0, g3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+  if (c0 < F) {
+    load4(gamma + c0, c0, F, false, g0, g1, g2, g3);
+    load4(beta + c0, c0, F, false, b0, b1, b2, b3);
+  }
+  for (int64_t row = (int64_t)blockIdx.x * RPB + wave * (64 / LPR) + sub; row < rows; row += (int64_t)gridDim.x * RPB) {
+    float x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+    if (c0 < F) load4(X + row * ldx + c0, c0, F, vx, x0, x1, x2, x3);
+    const float mean = group_sum<LPR>(x0 + x1 + x2 + x3) * invF;
+    const float d0 = (c0 < F) ? x0 - mean : 0.f, d1 = (c0 + 1 < F) ? x1 - mean : 0.f;
+    const float d2 = (c0 + 2 < F) ? x2 - mean : 0.f, d3 = (c0 + 3 < F) ? x3 - mean : 0.f;
+    const float var = group_sum<LPR>(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * invF;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (c0 < F)
+      store4(Y + row * ldy + c0, c0, F, vy, d0 * rstd * g0 + b0, d1 * rstd * g1 + b1, d2 * rstd * g2 + b2,
+             d3 * rstd * g3 + b3);
+    if (l == 0 && stats) {
+      stats[2 * row] = mean;
+      stats[2 * row + 1] = rstd;
+    }
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma;  partial dgamma/dbeta per block
+template <int LPR>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dY, int64_t lddy,
+                                                     const float* __restrict__ X, int64_t ldx,
+                                                     const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                     float* __restrict__ dX, int64_t lddx, float* __restrict__ part,
+                                                     int64_t rows, int32_t F, int32_t FP, int32_t vdy, int32_t vx,
+                                                     int32_t vdx) {
+  constexpr int RPW = 64 / LPR;
+  constexpr int RPB = RPW * 4;
+  __shared__ float red[RPB][LPR * 4 * 2 + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  const float invF = 1.f / (float)F;
+  float g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+  if (c0 < F) load4(gamma + c0, c0, F, false, g0, g1, g2, g3);
+  float dg0 = 0, dg1 = 0, dg2 = 0, dg3 = 0, db0 = 0, db1 = 0, db2 = 0, db3 = 0;
+  for (int64_t row = (int64_t)blockIdx.x * RPB + wave * RPW + sub; row < rows; row += (int64_t)gridDim.x * RPB) {
+    float x0 = 0, x1 = 0, x2 = 0, x3 = 0, y0 = 0, y1 = 0, y2 = 0, y3 = 0;
+    if (c0 < F) {
+      load4(X + row * ldx + c0, c0, F, vx, x0, x1, x2, x3);
+      load4(dY + row * lddy + c0, c0, F, vdy, y0, y1, y2, y3);
+    }
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    const float h0 = (c0 < F) ? (x0 - mean) * rstd : 0.f, h1 = (c0 + 1 < F) ? (x1 - mean) * rstd : 0.f;
+    const float h2 = (c0 + 2 < F) ? (x2 - mean) * rstd : 0.f, h3 = (c0 + 3 < F) ? (x3 - mean) * rstd : 0.f;
+    const float q0 = y0 * g0, q1 = y1 * g1, q2 = y2 * g2, q3 = y3 * g3;
+    const float m1 = group_sum<LPR>(q0 + q1 + q2 + q3) * invF;
+    const float m2 = group_sum<LPR>(q0 * h0 + q1 * h1 + q2 * h2 + q3 * h3) * invF;
+    if (c0 < F)
+      store4(dX + row * lddx + c0, c0, F, vdx, rstd * (q0 - m1 - h0 * m2), rstd * (q1 - m1 - h1 * m2),
+             rstd * (q2 - m1 - h2 * m2), rstd * (q3 - m1 - h3 * m2));
+    dg0 += y0 * h0; dg1 += y1 * h1; dg2 += y2 * h2; dg3 += y3 * h3;
+    db0 += y0; db1 += y1; db2 += y2; db3 += y3;
+  }
+  // reduce the RPB row groups of this block -> part[block][2*FP]  (dgamma | dbeta)
+  const int g = wave * RPW + sub;
+  float* r = red[g];
+  r[c0] = dg0; r[c0 + 1] = dg1; r[c0 + 2] = dg2; r[c0 + 3] = dg3;
+  r[LPR * 4 + c0] = db0; r[LPR * 4 + c0 + 1] = db1; r[LPR * 4 + c0 + 2] = db2; r[LPR * 4 + c0 + 3] = db3;
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * LPR * 4; idx += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < RPB; ++q) s += red[q][idx];
+    const int which = idx / (LPR * 4), c = idx % (LPR * 4);
+    if (c < F) part[(size_t)blockIdx.x * 2 * FP + which * FP + c] = s;
+  }
+}
+
+// column sums: part[block][FP]
+template <int LPR>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t ldx,
+                                                     float* __restrict__ part, int64_t rows, int32_t F, int32_t FP,
+                                                     int32_t vx) {
+  constexpr int RPW = 64 / LPR;
+  constexpr int RPB = RPW * 4;
+  __shared__ float red[RPB][LPR * 4 + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  if (c0 < F)
+    for (int64_t row = (int64_t)blockIdx.x * RPB + wave * RPW + sub; row < rows; row += (int64_t)gridDim.x * RPB) {
+      float x0, x1, x2, x3;
+      load4(X + row * ldx + c0, c0, F, vx, x0, x1, x2, x3);
+      s0 += x0; s1 += x1; s2 += x2; s3 += x3;
+    }
+  float* r = red[wave * RPW + sub];
+  r[c0] = s0; r[c0 + 1] = s1; r[c0 + 2] = s2; r[c0 + 3] = s3;
+  __syncthreads();
+  for (int c = threadIdx.x; c < F; c += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < RPB; ++q) s += red[q][c];
+    part[(size_t)blockIdx.x * FP + c] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_cols_kernel(const float* __restrict__ part, int32_t nparts,
+                                                          int32_t pstride, float* __restrict__ out, int32_t count,
+                                                          int32_t accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= count) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * pstride + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+constexpr int kNormBlocks = 1024;
+
+inline int lpr_for(int F) {
+  const int lanes = (F + 3) / 4;
+  return lanes <= 4 ? 4 : lanes <= 8 ? 8 : lanes <= 16 ? 16 : lanes <= 32 ? 32 : 64;
+}
+inline bool vec_ok(const float* p, int64_t ld, int F) { return (ld % 4 == 0) && gcl::aligned16(p) && ld >= ((F + 3) / 4) * 4; }
+inline bool vec_store_ok(const float* p, int64_t ld, int F) { return (ld % 4 == 0) && gcl::aligned16(p) && (F % 4 == 0); }
+
+}  // namespace
+
+#define GCL_DISPATCH_LPR(lpr, CALL) \
+  switch (lpr) {                    \
+    case 4: CALL(4); break;         \
+    case 8: CALL(8); break;         \
+    case 16: CALL(16); break;       \
+    case 32: CALL(32); break;       \
+    default: CALL(64); break;       \
+  }
+
+extern "C" int gcl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                 float* y, int64_t ldy, float* stats, int64_t rows, int32_t F, gcl_stream_t stream) {
+  GCL_CHECK_ARG(x && gamma && beta && y, "layernorm_fwd: null argument");
+  GCL_CHECK_ARG(F >= 1 && F <= 256 && ldx >= F && ldy >= F, "layernorm_fwd: bad shape F=%d", F);
+  if (rows == 0) return GCL_OK;
+  const int lpr = lpr_for(F);
+  const int rpb = (64 / lpr) * 4;
+  int64_t nb = gcl::cdiv(rows, rpb);
+  if (nb > 8192) nb = 8192;
+  const int vx = vec_ok(x, ldx, F), vy = vec_store_ok(y, ldy, F);
+#define CALL(L)                                                                                              \
+  hipLaunchKernelGGL((ln_fwd_kernel<L>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, \
+                     beta, eps, y, ldy, stats, rows, F, vx, vy)
+  GCL_DISPATCH_LPR(lpr, CALL)
+#undef CALL
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+extern "C" size_t gcl_layernorm_bwd_ws_bytes(int64_t rows, int32_t F) {
+  (void)rows;
+  const size_t FP = (size_t)((F + 3) / 4) * 4;
+  return (size_t)kNormBlocks * 2 * FP * sizeof(float);
+}
+
+extern "C" int gcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                                 const float* stats, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                                 int32_t accumulate, int64_t rows, int32_t F, void* ws, size_t ws_bytes,
+                                 gcl_stream_t stream) {
+  GCL_CHECK_ARG(dy && x && gamma && stats && dx && dgamma && dbeta, "layernorm_bwd: null argument");
+  GCL_CHECK_ARG(F >= 1 && F <= 256 && ldx >= F && lddy >= F && lddx >= F, "layernorm_bwd: bad shape F=%d", F);
+  GCL_CHECK_ARG(ws && ws_bytes >= gcl_layernorm_bwd_ws_bytes(rows, F), "layernorm_bwd: workspace too small");
+  if (rows == 0) return GCL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int lpr = lpr_for(F);
+  const int rpb = (64 / lpr) * 4;
+  const int FP = ((F + 3) / 4) * 4;
+  int64_t nb = gcl::cdiv(rows, rpb);
+  if (nb > kNormBlocks) nb = kNormBlocks;
+  float* part = (float*)ws;
+  const int vdy = vec_ok(dy, lddy, F), vx = vec_ok(x, ldx, F), vdx = vec_store_ok(dx, lddx, F);
+#define CALL(L)                                                                                                   \
+  hipLaunchKernelGGL((ln_bwd_kernel<L>), dim3((unsigned)nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma, stats, dx, \
+                     lddx, part, rows, F, FP, vdy, vx, vdx)
+  GCL_DISPATCH_LPR(lpr, CALL)
+#undef CALL
+  GCL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)gcl::cdiv(F, 256)), dim3(256), 0, st, part, (int)nb, 2 * FP,
+                     dgamma, F, accumulate);
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)gcl::cdiv(F, 256)), dim3(256), 0, st, part + FP, (int)nb,
+                     2 * FP, dbeta, F, accumulate);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+extern "C" size_t gcl_colsum_ws_bytes(int64_t rows, int32_t F) {
+  (void)rows;
+  return (size_t)kNormBlocks * (size_t)(((F + 3) / 4) * 4) * sizeof(float);
+}
+
+extern "C" int gcl_colsum(const float* x, int64_t ldx, int64_t rows, int32_t F, float* out, int32_t accumulate,
+                          void* ws, size_t ws_bytes, gcl_stream_t stream) {
+  GCL_CHECK_ARG(x && out, "colsum: null argument");
+  GCL_CHECK_ARG(F >= 1 && F <= 256 && ldx >= F, "colsum: bad shape F=%d", F);
+  GCL_CHECK_ARG(ws && ws_bytes >= gcl_colsum_ws_bytes(rows, F), "colsum: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int lpr = lpr_for(F);
+  const int rpb = (64 / lpr) * 4;
+  const int FP = ((F + 3) / 4) * 4;
+  int64_t nb = gcl::cdiv(rows > 0 ? rows : 1, rpb);
+  if (nb > kNormBlocks) nb = kNormBlocks;
+  float* part = (float*)ws;
+  const int vx = vec_ok(x, ldx, F);
+#define CALL(L) \
+  hipLaunchKernelGGL((colsum_kernel<L>), dim3((unsigned)nb), dim3(256), 0, st, x, ldx, part, rows, F, FP, vx)
+  GCL_DISPATCH_LPR(lpr, CALL)
+#undef CALL
+  GCL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)gcl::cdiv(F, 256)), dim3(256), 0, st, part, (int)nb, FP, out, F,
+                     accumulate);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}

@@ -1,0 +1,348 @@
+"""ctypes binding of `libgcl_hip.so` (C ABI: `include/gcl.h`).
+
+PyTorch tensors are containers only: every wrapper hands raw device pointers, leading dimensions
+and the current HIP stream to the library.  There is NO CPU fallback - if the shared library is
+missing or a tensor is not on a GPU the call raises.
+"""
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgcl_hip.so")
+
+GRAPH_GCN, GRAPH_GAT, GRAPH_MEAN = 0, 1, 2
+
+_lib = None
+
+_i32, _i64, _f32, _vp, _sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol declared in include/gcl.h
+_SIGNATURES = {
+    "gcl_version": (C.c_int, []),
+    "gcl_last_error": (C.c_char_p, []),
+    "gcl_graph_count_edges": (C.c_int, [_vp, _i64, _i32, _i32, C.POINTER(_i64)]),
+    "gcl_graph_build_host": (C.c_int, [_vp, _i64, _i32, _i32] + [_vp] * 8),
+    "gcl_graph_create": (C.c_int, [_vp, _i64, _i32, _i32, C.POINTER(_vp)]),
+    "gcl_graph_destroy": (None, [_vp]),
+    "gcl_graph_num_nodes": (_i32, [_vp]),
+    "gcl_graph_num_edges": (_i64, [_vp]),
+    "gcl_graph_max_in_degree": (_i32, [_vp]),
+    "gcl_graph_export_edges": (C.c_int, [_vp, _vp]),
+    "gcl_graph_eperm_device": (_vp, [_vp]),
+    "gcl_linear_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "gcl_linear_bwd_dx": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _sz, _vp]),
+    "gcl_linear_bwd_dw": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "gcl_linear_bwd_ws_bytes": (_sz, [_i64, _i32, _i32]),
+    "gcl_aggregate": (C.c_int, [_vp, _i32, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "gcl_gat_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "gcl_gat_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
+                              _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "gcl_gat_bwd_ws_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
+    "gcl_gat_alpha_to_edge_order": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
+    "gcl_gat_prune": (C.c_int, [_vp, _vp, _f32, _vp, C.POINTER(_i64), _vp, _sz, _vp]),
+    "gcl_gat_prune_ws_bytes": (_sz, [_i64]),
+    "gcl_layernorm_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _vp, _i64, _vp, _i64, _i32, _vp]),
+    "gcl_layernorm_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i64, _i32, _vp, _sz, _vp]),
+    "gcl_layernorm_bwd_ws_bytes": (_sz, [_i64, _i32]),
+    "gcl_graphnorm_fwd": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _f32, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "gcl_graphnorm_bwd": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f32, _vp, _i64, _i64, _vp, _vp,
+                                    _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "gcl_graphnorm_ws_bytes": (_sz, [_i32, _i32, _i32]),
+    "gcl_colsum": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
+    "gcl_colsum_ws_bytes": (_sz, [_i64, _i32]),
+    "gcl_assemble_input": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "gcl_wmse_fwd_bwd": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f32, _f32, _vp,
+                                   _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "gcl_wmse_ws_bytes": (_sz, [_i32, _i32, _i32]),
+    "gcl_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
+    "gcl_copy_rows": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+}
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """The loaded shared library; raises loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C graphcast-lite_amd/csrc`). The HIP path has no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise RuntimeError(f"libgcl_hip error {rc}: {lib().gcl_last_error().decode()}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libgcl_hip needs GPU tensors (there is no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"libgcl_hip needs float32 tensors, got {t.dtype}")
+    return t.data_ptr()
+
+
+_ws = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only per-device scratch buffer (uint8)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    cur = _ws.get(key)
+    if cur is None or cur.numel() < nbytes:
+        cur = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=f"cuda:{key}")
+        _ws[key] = cur
+    return cur
+
+
+def rows2d(t: torch.Tensor) -> torch.Tensor:
+    """View `[..., F]` as `[rows, F]` with a single row stride; copies only if it must."""
+    if t.dim() == 2 and t.stride(1) == 1:
+        return t
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return t.view(-1, t.shape[-1])
+
+
+class Graph:
+    """Device CSR (+transpose) of a reference-layout `edge_index` (int64 `[2,E]`, CPU or GPU)."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, kind: int):
+        ei = edge_index.detach().to("cpu", torch.int64).contiguous()
+        if ei.dim() != 2 or ei.shape[0] != 2:
+            raise ValueError(f"edge_index must be [2, E], got {tuple(ei.shape)}")
+        self.kind = kind
+        self._h = _vp()
+        _check(lib().gcl_graph_create(ei.data_ptr(), ei.shape[1], int(num_nodes), kind, C.byref(self._h)))
+        self.n = int(num_nodes)
+        self.e = int(lib().gcl_graph_num_edges(self._h))
+        self.max_in_degree = int(lib().gcl_graph_max_in_degree(self._h))
+        # PyG-order edge list with loops, as a tensor with a STABLE identity: when the input already
+        # is that list (SparseGATConv feeds its own output back, src/models.py:846) the input tensor
+        # itself is returned, so the CSR cache keeps hitting instead of rebuilding every step.
+        self._exported = {}
+        if ei.shape[1] == self.e and torch.equal(self.export_edges(), ei):
+            self._exported[str(edge_index.device)] = edge_index
+
+    @property
+    def handle(self):
+        return self._h
+
+    def export_edges(self) -> torch.Tensor:
+        out = torch.empty(2, self.e, dtype=torch.int64)
+        _check(lib().gcl_graph_export_edges(self._h, out.data_ptr()))
+        return out
+
+    def edges_with_loops(self, device) -> torch.Tensor:
+        key = str(torch.device(device))
+        t = self._exported.get(key)
+        if t is None:
+            t = self.export_edges().to(device)
+            self._exported[key] = t
+        return t
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().gcl_graph_destroy(self._h)
+                self._h = _vp()
+        except Exception:
+            pass
+
+
+def build_csr_host(edge_index: torch.Tensor, num_nodes: int, kind: int):
+    """CPU-only CSR construction (no GPU needed) - returns a dict of torch CPU tensors."""
+    ei = edge_index.detach().to("cpu", torch.int64).contiguous()
+    e_out = _i64(0)
+    _check(lib().gcl_graph_count_edges(ei.data_ptr(), ei.shape[1], int(num_nodes), kind, C.byref(e_out)))
+    Ep, n = e_out.value, int(num_nodes)
+    i32 = lambda k: torch.zeros(max(k, 1), dtype=torch.int32)
+    f32 = lambda k: torch.zeros(max(k, 1), dtype=torch.float32)
+    out = dict(rowptr=i32(n + 1), col=i32(Ep), w=f32(Ep), eperm=i32(Ep), trowptr=i32(n + 1), tcol=i32(Ep),
+               tw=f32(Ep), tslot=i32(Ep))
+    _check(lib().gcl_graph_build_host(
+        ei.data_ptr(), ei.shape[1], n, kind, out["rowptr"].data_ptr(), out["col"].data_ptr(), out["w"].data_ptr(),
+        out["eperm"].data_ptr(), out["trowptr"].data_ptr(), out["tcol"].data_ptr(), out["tw"].data_ptr(),
+        out["tslot"].data_ptr()))
+    for k in ("col", "w", "eperm", "tcol", "tw", "tslot"):
+        out[k] = out[k][:Ep]
+    out["num_edges"] = Ep
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# raw wrappers (no autograd).  2-D tensors are [rows, F] with stride (ld, 1).
+# ------------------------------------------------------------------------------------------------
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a [rows, F] view with unit channel stride"
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def linear_fwd(x, W, bias, in_slope, out=None, ld_out=None):
+    rows, Fin = x.shape
+    Fout = W.shape[0]
+    if out is None:
+        ld = ld_out or Fout
+        out = torch.empty(rows, ld, dtype=torch.float32, device=x.device)[:, :Fout]
+    _check(lib().gcl_linear_fwd(_p(x), _ld(x), _p(in_slope), _p(W), _p(bias), _p(out), _ld(out), rows, Fin, Fout, _stream()))
+    return out
+
+
+def linear_bwd_dx(dy, W, x, in_slope, d_in_slope):
+    rows, Fout = dy.shape
+    Fin = W.shape[1]
+    dx = torch.empty(rows, Fin, dtype=torch.float32, device=dy.device)
+    nb = lib().gcl_linear_bwd_ws_bytes(rows, Fin, Fout)
+    ws = workspace(nb, dy.device)
+    _check(lib().gcl_linear_bwd_dx(
+        _p(dy), _ld(dy), _p(W), _p(x) if in_slope is not None else None, _ld(x) if in_slope is not None else 0,
+        _p(in_slope), _p(d_in_slope), _p(dx), Fin, rows, Fin, Fout, ws.data_ptr(), ws.numel(), _stream()))
+    return dx
+
+
+def linear_bwd_dw(dy, x, in_slope, dW, db, accumulate: bool):
+    rows, Fout = dy.shape
+    Fin = x.shape[1]
+    nb = lib().gcl_linear_bwd_ws_bytes(rows, Fin, Fout)
+    ws = workspace(nb, dy.device)
+    _check(lib().gcl_linear_bwd_dw(_p(dy), _ld(dy), _p(x), _ld(x), _p(in_slope), _p(dW), _p(db), rows, Fin, Fout,
+                                   1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()))
+
+
+def aggregate(graph: Graph, h3, bias, transpose=False, out=None):
+    """h3: [B, n, F] with unit channel stride; returns [B, n, F]."""
+    B, n, F = h3.shape
+    assert n == graph.n, f"graph has {graph.n} nodes, features have {n} rows"
+    assert h3.stride(2) == 1
+    if out is None:
+        out = torch.empty(B, n, F, dtype=torch.float32, device=h3.device)
+    _check(lib().gcl_aggregate(graph.handle, 1 if transpose else 0, _p(h3), h3.stride(1), h3.stride(0), _p(bias),
+                               _p(out), out.stride(1), out.stride(0), B, F, _stream()))
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    rows, F = x.shape
+    y = torch.empty(rows, F, dtype=torch.float32, device=x.device)
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+    _check(lib().gcl_layernorm_fwd(_p(x), _ld(x), _p(gamma), _p(beta), float(eps), _p(y), F, _p(stats), rows, F, _stream()))
+    return y, stats
+
+
+def layernorm_bwd(dy, x, gamma, stats, dgamma, dbeta, accumulate: bool):
+    rows, F = x.shape
+    dx = torch.empty(rows, F, dtype=torch.float32, device=x.device)
+    nb = lib().gcl_layernorm_bwd_ws_bytes(rows, F)
+    ws = workspace(nb, x.device)
+    _check(lib().gcl_layernorm_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), _p(stats), _p(dx), F, _p(dgamma),
+                                   _p(dbeta), 1 if accumulate else 0, rows, F, ws.data_ptr(), ws.numel(), _stream()))
+    return dx
+
+
+def colsum(x, out, accumulate: bool):
+    rows, F = x.shape
+    nb = lib().gcl_colsum_ws_bytes(rows, F)
+    ws = workspace(nb, x.device)
+    _check(lib().gcl_colsum(_p(x), _ld(x), rows, F, _p(out), 1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()))
+    return out
+
+
+def gat_fwd(graph: Graph, h3, att_src, att_dst, bias, H, Cc, need_alpha=True):
+    B, n, HC = h3.shape
+    dev = h3.device
+    a_s = torch.empty(B, n, H, dtype=torch.float32, device=dev)
+    a_d = torch.empty(B, n, H, dtype=torch.float32, device=dev)
+    alpha = torch.empty(B, graph.e, H, dtype=torch.float32, device=dev) if need_alpha else None
+    y = torch.empty(B, n, Cc, dtype=torch.float32, device=dev)
+    _check(lib().gcl_gat_fwd(graph.handle, _p(h3), h3.stride(1), h3.stride(0), _p(att_src), _p(att_dst), _p(bias),
+                             _p(a_s), _p(a_d), _p(alpha), _p(y), Cc, n * Cc, B, H, Cc, _stream()))
+    return y, a_s, a_d, alpha
+
+
+def gat_bwd(graph: Graph, dy3, h3, att_src, att_dst, a_s, a_d, alpha, d_att_src, d_att_dst, d_bias, accumulate, H, Cc):
+    B, n, HC = h3.shape
+    dy3 = dy3.contiguous()
+    dh = torch.empty(B, n, HC, dtype=torch.float32, device=h3.device)
+    nb = lib().gcl_gat_bwd_ws_bytes(graph.e, n, B, H, Cc)
+    ws = workspace(nb, h3.device)
+    _check(lib().gcl_gat_bwd(graph.handle, _p(dy3), Cc, n * Cc, _p(h3), h3.stride(1), h3.stride(0), _p(att_src),
+                             _p(att_dst), _p(a_s), _p(a_d), _p(alpha), _p(dh), HC, n * HC, _p(d_att_src), _p(d_att_dst),
+                             _p(d_bias), 1 if accumulate else 0, B, H, Cc, ws.data_ptr(), ws.numel(), _stream()))
+    return dh
+
+
+def gat_alpha_edge_order(graph: Graph, alpha_slots_1sample, H):
+    out = torch.empty(graph.e, H, dtype=torch.float32, device=alpha_slots_1sample.device)
+    _check(lib().gcl_gat_alpha_to_edge_order(graph.handle, _p(alpha_slots_1sample.contiguous()), _p(out), H, _stream()))
+    return out
+
+
+def gat_prune(graph: Graph, alpha_edges, threshold: float) -> torch.Tensor:
+    """Surviving PyG-order edge list (CPU int64 `[2, kept]`)."""
+    buf = torch.empty(2 * graph.e, dtype=torch.int64)
+    kept = _i64(0)
+    nb = lib().gcl_gat_prune_ws_bytes(graph.e)
+    ws = workspace(nb, alpha_edges.device)
+    _check(lib().gcl_gat_prune(graph.handle, _p(alpha_edges.contiguous()), float(threshold), buf.data_ptr(),
+                               C.byref(kept), ws.data_ptr(), ws.numel(), _stream()))
+    k = kept.value
+    return buf[: 2 * k].view(2, k).clone()
+
+
+def assemble_input(x3, grid_static, mesh_static):
+    B, G, Cdyn = x3.shape
+    M, Cs = mesh_static.shape
+    x3 = x3.contiguous()
+    out = torch.empty(B, G + M, Cdyn + Cs, dtype=torch.float32, device=x3.device)
+    _check(lib().gcl_assemble_input(_p(x3), _p(grid_static), _p(mesh_static), _p(out), Cdyn + Cs, B, G, M, Cdyn, Cs, _stream()))
+    return out
+
+
+def wmse_fwd_bwd(delta3, x_last3, y3, node_w, chan_w, inv_wsum, grad_scale, want_grad=True, want_state=False):
+    """delta3 [B,G,C] contiguous; x_last3 / y3 may be strided views (unit channel stride)."""
+    B, G, Cc = delta3.shape
+    dev = delta3.device
+    delta3 = delta3.contiguous()
+    dd = torch.empty(B, G, Cc, dtype=torch.float32, device=dev) if want_grad else None
+    st = torch.empty(B, G, Cc, dtype=torch.float32, device=dev) if want_state else None
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    nb = lib().gcl_wmse_ws_bytes(B, G, Cc)
+    ws = workspace(nb, dev)
+    xl = x_last3
+    _check(lib().gcl_wmse_fwd_bwd(
+        _p(delta3), Cc, G * Cc, _p(xl), xl.stride(1) if xl is not None else 0, xl.stride(0) if xl is not None else 0,
+        _p(y3), y3.stride(1), y3.stride(0), _p(node_w), _p(chan_w), float(inv_wsum), float(grad_scale), _p(dd), _p(st),
+        _p(loss), B, G, Cc, ws.data_ptr(), ws.numel(), _stream()))
+    return loss, dd, st
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _check(lib().gcl_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, int(step),
+                               float(grad_scale), _stream()))
+
+
+def copy_rows(src3, dst3):
+    B, rows, F = src3.shape
+    _check(lib().gcl_copy_rows(_p(src3), src3.stride(1), src3.stride(0), _p(dst3), dst3.stride(1), dst3.stride(0), B, rows, F, _stream()))
+    return dst3

@@ -1,0 +1,423 @@
+"""Module API of the reference's `src/models.py`, executed by hand-written gfx950 kernels.
+
+Same class names, constructor arguments, attribute names and state-dict keys as the reference
+ so that `src/train.py`-style callers and reference checkpoints work unchanged:
+
+  MLP               src/models.py:54-109     `MLP.{i}.weight|bias`
+  SparseGATConv     src/models.py:112-151
+  GraphLayer        src/models.py:289-440    `activation.weight`, `layers.{i}.lin.weight|bias|att_*`
+  Model             src/models.py:443-473    `mlp.*`, `graph_layer.*`
+  WeatherPrediction src/models.py:476-927    `encoder|processor|decoder.*`, `_processing_edge_features`
+
+What is new relative to the reference (documented deviations):
+  * a batch dimension: `[B, G, C]` is B independent samples (the reference only runs B = 1 because
+    of its `X.squeeze()`); `[1, G, C]` / `[G, C]` still return `[G, C_out]`;
+  * graph normalisation (`gcn_norm`, self-loop handling, degree counts) is done once per graph
+    when the CSR handle is built, not on every forward;
+  * the three `summary()` forward passes of the constructor are skipped.
+Compute runs only on a GPU through `libgcl_hip.so`; there is no CPU path in this package.
+"""
+import math
+from collections import OrderedDict
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+from .config import (
+    DataConfig,
+    GraphBlock,
+    GraphBuildingConfig,
+    GraphLayerType,
+    MLPBlock,
+    ModelConfig,
+    PipelineConfig,
+)
+from .create_graphs import create_decoding_graph, create_encoding_graph, create_processing_graph
+from .functional import AssembleFn, GATLayerFn, GCNStackFn, LayerNormFn, MeanAggFn, MLPFn
+from .mesh import get_hierarchy_of_triangular_meshes_for_sphere, get_mesh_lat_long, prune_mesh_to_region
+
+
+# ------------------------------------------------------------------------------------------------
+# CSR handle cache: modules receive reference-layout `edge_index` tensors (the reference API) and
+# look the device CSR up by tensor identity + version, so normalisation is paid once per graph.
+# ------------------------------------------------------------------------------------------------
+class _GraphCache:
+    def __init__(self, capacity: int = 32):
+        self._d = OrderedDict()
+        self._cap = capacity
+
+    def get(self, edge_index: torch.Tensor, n: int, kind: int) -> hip.Graph:
+        key = (id(edge_index), edge_index._version, tuple(edge_index.shape), int(n), kind)
+        hit = self._d.get(key)
+        if hit is not None:
+            self._d.move_to_end(key)
+            return hit[1]
+        g = hip.Graph(edge_index, n, kind)
+        self._d[key] = (edge_index, g)  # keep the tensor alive so its id cannot be reused
+        if len(self._d) > self._cap:
+            self._d.popitem(last=False)
+        return g
+
+
+_graphs = _GraphCache()
+
+
+def _glorot_(t: torch.Tensor):
+    a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+    with torch.no_grad():
+        t.uniform_(-a, a)
+
+
+def _num_nodes(X: torch.Tensor) -> int:
+    return X.shape[-2]
+
+
+class LayerNorm(nn.Module):
+    """PyG `LayerNorm(in_channels, eps=1e-5, affine=True, mode)` parameter holder + node-mode kernel."""
+
+    def __init__(self, in_channels: int, eps: float = 1e-5, affine: bool = True, mode: str = "graph"):
+        super().__init__()
+        self.in_channels, self.eps, self.mode = in_channels, eps, mode or "graph"
+        self.weight = nn.Parameter(torch.ones(in_channels))
+        self.bias = nn.Parameter(torch.zeros(in_channels))
+
+    def forward(self, x):
+        if self.mode != "node":
+            raise NotImplementedError(
+                'LayerNorm(mode="graph") is not on the HIP path yet (no BASELINE config uses it)')
+        return LayerNormFn.apply(x, self, self.eps, self.weight, self.bias)
+
+
+class GCNConv(nn.Module):
+    """Parameter holder with PyG GCNConv's keys (`lin.weight` [out,in], `bias` [out])."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        _glorot_(self.lin.weight)
+
+    def forward(self, x, edge_index):
+        g = _graphs.get(edge_index, _num_nodes(x), hip.GRAPH_GCN)
+        return GCNStackFn.apply(x, self, g, 1, False, 1e-5, self.lin.weight, self.bias, None)
+
+
+class GATConv(nn.Module):
+    """Parameter holder with PyG 2.5 GATConv's keys (`lin.weight` [H*C,in], `att_src`, `att_dst`
+    [1,H,C], `bias` [C]); `concat=False` only, as the reference uses it (src/models.py:336,364)."""
+
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = False,
+                 dropout: float = 0.0, bias: bool = True, **kwargs):
+        super().__init__()
+        if concat or dropout != 0.0 or not bias:
+            raise NotImplementedError("only GATConv(concat=False, dropout=0, bias=True) is on the HIP path")
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.lin = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        _glorot_(self.lin.weight)
+        _glorot_(self.att_src)
+        _glorot_(self.att_dst)
+
+    def _run(self, x, edge_index, slope, want_alpha):
+        g = _graphs.get(edge_index, _num_nodes(x), hip.GRAPH_GAT)
+        y, alpha = GATLayerFn.apply(x, self, g, self.heads, want_alpha, slope, self.lin.weight, self.att_src,
+                                    self.att_dst, self.bias)
+        return y, alpha, g
+
+    def forward(self, x, edge_index, return_attention_weights: bool = False):
+        y, alpha, g = self._run(x, edge_index, None, return_attention_weights)
+        if return_attention_weights:
+            return y, (g.edges_with_loops(x.device), alpha)
+        return y
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # older PyG stored two aliases lin_src / lin_dst instead of one lin
+        src, dst, lin = prefix + "lin_src.weight", prefix + "lin_dst.weight", prefix + "lin.weight"
+        if lin not in state_dict and src in state_dict:
+            state_dict[lin] = state_dict.pop(src)
+            state_dict.pop(dst, None)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+class SparseGATConv(GATConv):
+    """`src/models.py:112-151`: GAT that also returns the (optionally pruned) edge list."""
+
+    def forward(self, x, edge_index, attention_threshold=0.0, **kwargs):
+        batch_num = kwargs.get("batch_num", 1)
+        slope = kwargs.get("_in_slope", None)
+        out, alpha_edges, g = self._run(x, edge_index, slope, True)
+        alpha = alpha_edges.squeeze()  # [E'] for heads == 1, as in the reference
+        if batch_num == 0:
+            print("edge_index", torch.Size([2, g.e]))
+            new_ei = hip.gat_prune(g, alpha, float(attention_threshold)).to(x.device)
+            mask = alpha >= attention_threshold
+            return out, (new_ei, alpha[mask])
+        return out, (g.edges_with_loops(x.device), alpha)
+
+
+class SimpleConv(nn.Module):
+    """PyG `SimpleConv(aggr="mean")` (no parameters)."""
+
+    def __init__(self, aggr: str = "mean"):
+        super().__init__()
+        if aggr != "mean":
+            raise NotImplementedError("only SimpleConv(aggr='mean') is on the HIP path")
+        self.aggr = aggr
+
+    def forward(self, x, edge_index):
+        return MeanAggFn.apply(x, _graphs.get(edge_index, _num_nodes(x), hip.GRAPH_MEAN))
+
+
+def _get_activation(name: str = "prelu"):
+    if name == "prelu":
+        return nn.PReLU()
+    if name in ("swish", "silu", "relu"):
+        raise NotImplementedError(f"activation {name!r} is not on the HIP path (PReLU stacks only)")
+    raise ValueError(f"Unknown activation: {name}")
+
+
+class MLP(nn.Module):
+    """`src/models.py:54-109`."""
+
+    def __init__(self, mlp_config: MLPBlock, input_dim):
+        super().__init__()
+        hidden = list(mlp_config.mlp_hidden_dims or [])
+        self.MLP = nn.ModuleList()
+        d = input_dim
+        for hdim in hidden:
+            self.MLP.extend([nn.Linear(in_features=d, out_features=hdim), nn.PReLU()])
+            d = hdim
+        self.MLP.append(nn.Linear(in_features=d, out_features=mlp_config.output_dim))
+        self._has_ln = bool(mlp_config.use_layer_norm)
+        if self._has_ln:
+            self.MLP.append(LayerNorm(in_channels=mlp_config.output_dim, mode=mlp_config.layer_norm_mode))
+
+    def forward(self, X: torch.Tensor):
+        params = []
+        ln = None
+        for layer in self.MLP:
+            if isinstance(layer, nn.Linear):
+                params += [layer.weight, layer.bias]
+            elif isinstance(layer, nn.PReLU):
+                params.append(layer.weight)
+            else:
+                ln = layer
+        if ln is not None and ln.mode != "node":
+            y = MLPFn.apply(X, self, False, 1e-5, *params)
+            return ln(y)
+        if ln is not None:
+            params += [ln.weight, ln.bias]
+        return MLPFn.apply(X, self, ln is not None, ln.eps if ln is not None else 1e-5, *params)
+
+
+class GraphLayer(nn.Module):
+    """`src/models.py:289-440`."""
+
+    def __init__(self, graph_config: GraphBlock, input_dim):
+        super().__init__()
+        self.layer_type: GraphLayerType = graph_config.layer_type
+        self.output_dim = None
+        lt = graph_config.layer_type
+        if lt == GraphLayerType.SimpleConv:
+            self.output_dim = input_dim
+            self.layers = SimpleConv(aggr="mean")
+        elif lt in (GraphLayerType.ConvGCN, GraphLayerType.GATConv, GraphLayerType.SparseGATConv):
+            self.activation = _get_activation(graph_config.activation or "prelu")
+            self.output_dim = graph_config.output_dim
+            self.layers = nn.ModuleList()
+            hidden = list(graph_config.hidden_dims or [])
+            if lt == GraphLayerType.SparseGATConv:
+                self.num_heads = graph_config.gat_props.num_heads
+                print(graph_config.layer_type)
+                self.layers.append(SparseGATConv(input_dim, graph_config.output_dim, heads=self.num_heads, concat=False))
+            else:
+                if lt == GraphLayerType.GATConv:
+                    self.num_heads = graph_config.gat_props.num_heads
+                    mk = lambda i, o: GATConv(i, o, heads=self.num_heads, concat=False)
+                else:
+                    mk = GCNConv
+                dims = [input_dim] + hidden + [graph_config.output_dim]
+                for k in range(len(dims) - 1):
+                    self.layers.append(mk(dims[k], dims[k + 1]))
+                    if k < len(dims) - 2:
+                        self.layers.append(self.activation)  # one shared PReLU instance (src/models.py:316-328)
+            if graph_config.use_layer_norm:
+                self.layers.append(LayerNorm(in_channels=graph_config.output_dim, mode=graph_config.layer_norm_mode))
+        elif lt == GraphLayerType.InteractionNet:
+            raise NotImplementedError(
+                "InteractionNet is outside this build's hot path (SURVEY.md §8f next #1)")
+        else:
+            print(graph_config.layer_type)
+            raise NotImplementedError(f"Layer type {graph_config.layer_type} not supported.")
+
+    def _final_ln(self) -> Optional[LayerNorm]:
+        last = self.layers[len(self.layers) - 1]
+        return last if isinstance(last, LayerNorm) else None
+
+    def forward(self, X: torch.Tensor, edge_index: torch.Tensor, attention_threshold=0.0, **kwargs):
+        if self.layer_type == GraphLayerType.SimpleConv:
+            return self.layers(x=X, edge_index=edge_index)
+        n = _num_nodes(X)
+        ln = self._final_ln()
+        fuse_ln = ln is not None and ln.mode == "node"
+
+        if self.layer_type == GraphLayerType.ConvGCN:
+            convs = [m for m in self.layers if isinstance(m, GCNConv)]
+            params = []
+            for c in convs:
+                params += [c.lin.weight, c.bias]
+            params.append(self.activation.weight if len(convs) > 1 else None)
+            if fuse_ln:
+                params += [ln.weight, ln.bias]
+            g = _graphs.get(edge_index, n, hip.GRAPH_GCN)
+            X = GCNStackFn.apply(X, self, g, len(convs), fuse_ln, ln.eps if fuse_ln else 1e-5, *params)
+            if ln is not None and not fuse_ln:
+                X = ln(X)
+            return X
+
+        if self.layer_type == GraphLayerType.GATConv:
+            slope = None
+            for layer in self.layers:
+                if isinstance(layer, GATConv):
+                    X, _, _ = layer._run(X, edge_index, slope, False)
+                    slope = self.activation.weight  # next conv applies the shared PReLU on load
+                elif isinstance(layer, LayerNorm):
+                    X = layer(X)
+            return X
+
+        if self.layer_type == GraphLayerType.SparseGATConv:
+            for layer in self.layers:
+                if isinstance(layer, SparseGATConv):
+                    X, (edge_index, _) = layer.forward(X, edge_index, attention_threshold, **kwargs)
+                elif isinstance(layer, LayerNorm):
+                    X = layer(X)
+            return X, edge_index
+        raise NotImplementedError(f"Layer type {self.layer_type} not supported.")
+
+
+class Model(nn.Module):
+    """`src/models.py:443-473`: optional MLP then GraphLayer."""
+
+    def __init__(self, model_config: ModelConfig, input_dim: int):
+        super().__init__()
+        self.mlp = None
+        self.output_dim = None
+        graph_input_dim = input_dim
+        if model_config.mlp:
+            self.mlp = MLP(mlp_config=model_config.mlp, input_dim=input_dim)
+            graph_input_dim = model_config.mlp.output_dim
+        self.graph_layer = GraphLayer(graph_config=model_config.gcn, input_dim=graph_input_dim)
+        self.output_dim = self.graph_layer.output_dim
+
+    def forward(self, X: torch.Tensor, edge_index: torch.Tensor, attention_threshold=0.0, **kwargs):
+        if self.mlp:
+            X = self.mlp(X=X)
+        return self.graph_layer(X=X, edge_index=edge_index, attention_threshold=attention_threshold, **kwargs)
+
+
+class WeatherPrediction(nn.Module):
+    """`src/models.py:476-927`: encode (grid->mesh) / process (mesh) / decode (mesh->grid)."""
+
+    def __init__(
+        self,
+        cordinates: Tuple[np.ndarray, np.ndarray],
+        graph_config: GraphBuildingConfig,
+        pipeline_config: PipelineConfig,
+        data_config: DataConfig,
+        device,
+        region_bounds=None,
+        mesh_buffer: float = 15.0,
+        flat_grid: bool = False,
+    ):
+        super().__init__()
+        self.device = device
+        self.flat_grid = flat_grid
+        self.obs_window = data_config.obs_window_used
+        self.num_features = data_config.num_features_used
+        self.total_feature_size = self.num_features * self.obs_window
+        self.use_product_graph = pipeline_config.product_graph is not None
+        if self.use_product_graph:
+            raise NotImplementedError("the product-graph pre-encoder is outside this build's hot path (SURVEY.md K13)")
+
+        self._init_grid_properties(cordinates[0], cordinates[1], flat_grid)
+        self._init_mesh_properties(graph_config, region_bounds, mesh_buffer)
+        ptype = pipeline_config.processor.gcn.layer_type
+        self.using_sparse_gat = ptype == GraphLayerType.SparseGATConv
+        self.using_interaction_net = ptype == GraphLayerType.InteractionNet
+        self._total_nodes = self._num_grid_nodes + self._num_mesh_nodes
+
+        self.encoding_graph, self.init_grid_features, self.init_mesh_features = create_encoding_graph(
+            grid_node_lats=self._grid_lat, grid_node_longs=self._grid_lon, mesh_node_lats=self._mesh_nodes_lat,
+            mesh_node_longs=self._mesh_nodes_lon, mesh=self._finest_mesh, graph_building_config=graph_config,
+            num_grid_nodes=self._num_grid_nodes, flat_grid=self.flat_grid,
+        )
+        self.init_grid_features = self.init_grid_features.to(device)
+        self.init_mesh_features = self.init_mesh_features.to(device)
+        self._init_feature_size = self.init_grid_features.shape[1]
+
+        self.processing_graph, proc_edge_features = create_processing_graph(
+            meshes=self._meshes, mesh_levels=graph_config.mesh_levels, mesh_node_lats=self._mesh_nodes_lat,
+            mesh_node_longs=self._mesh_nodes_lon,
+        )
+        self.register_buffer("_processing_edge_features", proc_edge_features)
+        self.decoding_graph = create_decoding_graph(
+            cordinates=cordinates, mesh=self._finest_mesh, graph_building_config=graph_config,
+            num_grid_nodes=self._num_grid_nodes, flat_grid=self.flat_grid,
+        )
+
+        encoder_input_dim = self.total_feature_size + self._init_feature_size
+        self.encoder = Model(model_config=pipeline_config.encoder, input_dim=encoder_input_dim).to(device)
+        self.processor = Model(model_config=pipeline_config.processor, input_dim=self.encoder.output_dim).to(device)
+        self.decoder = Model(model_config=pipeline_config.decoder, input_dim=self.processor.output_dim).to(device)
+        self.encoding_graph = self.encoding_graph.to(device)
+        self.decoding_graph = self.decoding_graph.to(device)
+        self.processing_graph = self.processing_graph.to(device)
+        self._processing_edge_features = self._processing_edge_features.to(device)
+
+    def _init_grid_properties(self, grid_lat, grid_lon, flat_grid=False):
+        self._grid_lat = np.asarray(grid_lat).astype(np.float32)
+        self._grid_lon = np.asarray(grid_lon).astype(np.float32)
+        self._num_grid_nodes = len(grid_lat) if flat_grid else self._grid_lat.shape[0] * self._grid_lon.shape[0]
+
+    def _init_mesh_properties(self, graph_config, region_bounds=None, mesh_buffer: float = 15.0):
+        self._meshes = get_hierarchy_of_triangular_meshes_for_sphere(splits=max(graph_config.mesh_levels))
+        if region_bounds is not None:
+            lat_min, lat_max, lon_min, lon_max = region_bounds
+            self._meshes = prune_mesh_to_region(self._meshes, lat_min, lat_max, lon_min, lon_max, buffer_deg=mesh_buffer)
+        self._finest_mesh = self._meshes[-1]
+        self._num_mesh_nodes = len(self._finest_mesh.vertices)
+        lat, lon = get_mesh_lat_long(finest_mesh=self._finest_mesh)
+        self._mesh_nodes_lat, self._mesh_nodes_lon = lat.astype(np.float32), lon.astype(np.float32)
+
+    def _preprocess_input(self, grid_node_features: torch.Tensor):
+        """`src/models.py:776-806` in one kernel: [grid dyn | grid static ; 0 | mesh static]."""
+        return AssembleFn.apply(grid_node_features, self.init_grid_features, self.init_mesh_features)
+
+    def forward_with_latents(self, X: torch.Tensor, attention_threshold=0.0, **kwargs):
+        G = self._num_grid_nodes
+        if X.dim() == 3 and X.shape[0] == 1:
+            X = X.squeeze(0)  # reference: X.squeeze() with batch 1 (src/models.py:822)
+        X = self._preprocess_input(grid_node_features=X)
+        encoded = self.encoder.forward(X=X, edge_index=self.encoding_graph)
+        grid_node_features = encoded[..., :G, :]
+        mesh_node_features = encoded[..., G:, :]
+        if self.using_sparse_gat:
+            processed, new_edge_index = self.processor.forward(
+                X=mesh_node_features, edge_index=self.processing_graph, attention_threshold=attention_threshold,
+                **kwargs)
+            self.processing_graph = new_edge_index
+        else:
+            processed = self.processor.forward(
+                X=mesh_node_features, edge_index=self.processing_graph, attention_threshold=attention_threshold)
+        processed_features = torch.cat((grid_node_features, processed), dim=-2)
+        decoded = self.decoder.forward(X=processed_features, edge_index=self.decoding_graph)
+        return decoded[..., :G, :], grid_node_features, processed
+
+    def forward(self, X: torch.Tensor, attention_threshold=0.0, **kwargs):
+        return self.forward_with_latents(X, attention_threshold, **kwargs)[0]

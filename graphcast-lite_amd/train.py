@@ -1,0 +1,196 @@
+"""Training-step semantics of the reference's `src/train.py`, on the HIP path.
+
+`weighted_mse_loss`, `get_lat_weights`, `build_boundary_mask`, `update_attention_threshold` and
+`train_epoch` keep the reference's names, arguments and results (src/train.py:53-136,138-239).
+`TrainStep` is the data-parallel fast path used by `bench.py`: one flat parameter / gradient /
+Adam-state buffer, gradients accumulated in place by the backward kernels, ONE RCCL all-reduce of
+the flat gradient bucket per optimiser step, one fused Adam launch.
+"""
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import hip
+from .functional import WeightedMSEFn
+
+
+def get_lat_weights(lat_dim, lon_dim, device, flat_lats=None):
+    """cos(lat)/mean laid out as the reference lays it out (src/train.py:53-72), `[1, G, 1]`."""
+    if flat_lats is not None:
+        w = torch.cos(torch.deg2rad(torch.from_numpy(flat_lats.copy()).float()))
+        w = w / w.mean()
+        return w.view(1, -1, 1).to(device)
+    w = torch.cos(torch.deg2rad(torch.linspace(-90, 90, lat_dim)))
+    w = w / w.mean()
+    return w.view(1, -1).expand(lon_dim, lat_dim).reshape(-1).view(1, -1, 1).to(device)
+
+
+def build_boundary_mask(n_lon, n_lat, width, device):
+    """src/train.py:74-82."""
+    m = torch.zeros(n_lon, n_lat)
+    m[width:n_lon - width, width:n_lat - width] = 1.0
+    return m.reshape(1, -1, 1).to(device)
+
+
+def combine_spatial_masks(*masks):
+    out = None
+    for m in masks:
+        if m is not None:
+            out = m if out is None else out * m
+    return out
+
+
+def _loss_weights(G: int, C: int, lat_weights, channel_mask, spatial_mask, device):
+    """Per-node and per-channel factors of the reference's broadcast weight tensor and 1/sum(w)
+    for ONE sample (the caller multiplies by the batch size)."""
+    node_w = None
+    for t in (spatial_mask, lat_weights):
+        if t is not None:
+            t = t.reshape(-1).to(device=device, dtype=torch.float32)
+            node_w = t if node_w is None else node_w * t
+    chan_w = channel_mask.reshape(-1).to(device=device, dtype=torch.float32) if channel_mask is not None else None
+    s_node = node_w.double().sum().item() if node_w is not None else float(G)
+    s_chan = chan_w.double().sum().item() if chan_w is not None else float(C)
+    return (node_w.contiguous() if node_w is not None else None,
+            chan_w.contiguous() if chan_w is not None else None, s_node * s_chan)
+
+
+def weighted_mse_loss(pred, target, lat_weights=None, channel_mask=None, spatial_mask=None, x_last=None):
+    """src/train.py:85-102 as one kernel: sum(w (pred-target)^2) / max(sum(w), 1e-12).
+    `x_last` (extension) folds the residual add `pred = x_last + delta` into the same pass."""
+    if pred.dim() == 2:
+        pred, target = pred.unsqueeze(0), target.unsqueeze(0)
+    B, G, C = pred.shape
+    node_w, chan_w, wsum1 = _loss_weights(G, C, lat_weights, channel_mask, spatial_mask, pred.device)
+    inv = 1.0 / max(wsum1 * B, 1e-12)
+    return WeightedMSEFn.apply(pred, x_last, target, node_w, chan_w, inv)
+
+
+def update_attention_threshold(epoch, max_epochs=30, start_epoch=5, final_threshold=0.1356):
+    """src/train.py:132-136."""
+    if epoch < start_epoch:
+        return 0.0
+    if epoch > max_epochs + start_epoch:
+        return final_threshold
+    return min(final_threshold, (epoch - start_epoch) * final_threshold / (max_epochs - start_epoch))
+
+
+def batch_loss(model, X, y, threshold=0.0, epoch=0, batch_num=1, lat_weights=None, current_ar_steps=1,
+               channel_mask=None, spatial_mask=None, static_channels=None, forcing_channels=None,
+               use_residual=True):
+    """Loss of one batch as the reference's inner loop builds it (src/train.py:173-231)."""
+    N, G, _ = X.shape
+    obs = model.obs_window
+    C = X.shape[-1] // obs
+    steps_total = y.shape[-1] // C
+    y_steps = y.view(N, G, steps_total, C)
+    state = X.view(N, G, obs, C)
+    steps = min(current_ar_steps, steps_total)
+    loss = 0
+    for s in range(steps):
+        delta = model(X=state.reshape(N, G, -1), attention_threshold=threshold, epoch=epoch, batch_num=batch_num)
+        if delta.dim() == 2:
+            delta = delta.unsqueeze(0)
+        x_last = state[:, :, -1, :]
+        target = y_steps[:, :, s, :]
+        loss = loss + weighted_mse_loss(delta, target, lat_weights, channel_mask, spatial_mask,
+                                        x_last=x_last if use_residual else None)
+        if s + 1 < steps:  # roll the window forward (src/train.py:215-228)
+            out = (x_last + delta) if use_residual else delta
+            out = out.clone()
+            if static_channels:
+                for ch in static_channels:
+                    out[:, :, ch] = x_last[:, :, ch]
+            if forcing_channels:
+                for ch in forcing_channels:
+                    out[:, :, ch] = target[:, :, ch]
+            state = torch.cat([state[:, :, 1:, :], out.unsqueeze(2)], dim=2)
+    return loss / steps
+
+
+def train_epoch(model, train_dataloader, optimiser, loss_fn, device, threshold, epoch, lat_weights=None,
+                current_ar_steps=1, channel_mask=None, spatial_mask=None, static_channels=None,
+                forcing_channels=None, use_residual=True):
+    """src/train.py:138-239 (same signature; `loss_fn` is unused there as well)."""
+    model.train()
+    total = 0.0
+    for i, (X, y) in enumerate(train_dataloader):
+        y = y.squeeze(0) if y.dim() == 4 else y
+        X, y = X.to(device), y.to(device)
+        optimiser.zero_grad()
+        loss = batch_loss(model, X, y, threshold, epoch, i, lat_weights, current_ar_steps, channel_mask,
+                          spatial_mask, static_channels, forcing_channels, use_residual)
+        loss.backward()
+        optimiser.step()
+        total += loss.detach().item()
+    return total / max(len(train_dataloader), 1)
+
+
+class FlatParams:
+    """All trainable parameters of a module re-pointed into ONE flat fp32 buffer, with a flat
+    gradient buffer whose slices are installed as `.grad` (so the backward kernels accumulate
+    straight into the all-reduce bucket)."""
+
+    def __init__(self, module: torch.nn.Module):
+        seen, self.params = set(), []
+        for p in module.parameters():
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                self.params.append(p)
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view(p.shape)
+            p.grad = self.grad[off:off + k].view(p.shape)
+            off += k
+        self.numel = total
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+class FusedAdam:
+    """torch.optim.Adam(lr, betas, eps, weight_decay=0) semantics over a FlatParams bucket."""
+
+    def __init__(self, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.flat, self.lr, self.betas, self.eps, self.wd = flat, lr, betas, eps, weight_decay
+        self.m = torch.zeros_like(flat.flat)
+        self.v = torch.zeros_like(flat.flat)
+        self.t = 0
+
+    def step(self, grad_scale: float = 1.0):
+        self.t += 1
+        hip.adam_step(self.flat.flat, self.flat.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1],
+                      self.eps, self.wd, self.t, grad_scale)
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+
+class TrainStep:
+    """One optimiser step on a local batch: forward, loss, backward, [all-reduce], Adam."""
+
+    def __init__(self, model, lr=1e-3, lat_weights=None, channel_mask=None, spatial_mask=None, use_residual=True,
+                 ar_steps=1, world_size=1):
+        self.model = model
+        self.flat = FlatParams(model)
+        self.opt = FusedAdam(self.flat, lr=lr)
+        self.lat_weights, self.channel_mask, self.spatial_mask = lat_weights, channel_mask, spatial_mask
+        self.use_residual, self.ar_steps, self.world = use_residual, ar_steps, world_size
+
+    def __call__(self, X, y, threshold=0.0, epoch=0, batch_num=1):
+        self.flat.zero_grad()
+        loss = batch_loss(self.model, X, y, threshold, epoch, batch_num, self.lat_weights, self.ar_steps,
+                          self.channel_mask, self.spatial_mask, None, None, self.use_residual)
+        loss.backward()
+        if self.world > 1:
+            # C1: the only collective on the path - one flat bucket, sum over ranks, mean via grad_scale
+            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)
+        self.opt.step(grad_scale=1.0 / self.world)
+        return loss.detach()

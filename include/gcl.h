@@ -1,0 +1,218 @@
+/*
+ * gcl.h - C ABI of libgcl_hip.so: graphcast-lite's encode-process-decode GNN hot path as
+ * hand-written gfx950 (MI355X / CDNA4) HIP kernels.
+ *
+ * The reference (ArturKKK/graphcast-lite) has no native boundary: its hot path is Python calling
+ * torch / torch_geometric ops from src/models.py.  Each entry point below names the reference
+ * call site whose stock-op expansion it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  Every function returns 0 on success
+ *     or a negative GCL_E* code; gcl_last_error() returns a thread-local message.
+ *   - Compute entry points never allocate, never synchronise and never create streams: the caller
+ *     passes device pointers it owns (contiguous fp32 / int32), explicit leading dimensions, a
+ *     workspace where one is needed (size from the matching *_ws_bytes query) and the hipStream_t
+ *     to enqueue on (as void*).  They are re-entrant; the only state is the immutable graph handle.
+ *   - Node features are row-major `[B, n, F]`: `ld*` = floats between consecutive rows,
+ *     `bs*` = floats between consecutive samples.  B independent samples share one graph.
+ *   - Activation chaining: buffers passed between layers hold PRE-activation values.  An entry
+ *     point that takes `in_slope` (device pointer to one float, may be NULL) applies
+ *     PReLU(x) = max(0,x) + slope*min(0,x) to its input while loading it, and its backward returns
+ *     the gradient with respect to the PRE-activation input (and adds the slope gradient into
+ *     `d_in_slope`).  This is how the reference's `conv -> shared PReLU -> conv` stacks
+ *     (src/models.py:321-330,416-421) and `Linear -> PReLU -> Linear` chains (src/models.py:61-109)
+ *     run without a separate activation pass.
+ */
+#ifndef GCL_H
+#define GCL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCL_VERSION 100 /* 0.1.0 */
+
+#define GCL_OK 0
+#define GCL_EINVAL (-1)   /* bad argument (shape, alignment, null pointer) */
+#define GCL_EHIP (-2)     /* HIP runtime error (message has the hipError string) */
+#define GCL_ENOMEM (-3)   /* workspace too small / allocation failed in graph_create */
+#define GCL_EUNSUPPORTED (-4)
+
+typedef struct gcl_graph gcl_graph_t; /* opaque; owns device CSR arrays */
+typedef void* gcl_stream_t;           /* hipStream_t */
+
+int gcl_version(void);
+const char* gcl_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Graph handle: reference-layout edge list -> receiver-sorted CSR (+ sender-sorted transpose).
+ * Replaces, once per graph instead of once per forward: add_remaining_self_loops + degree
+ * scatter_add + pow(-1/2) + two gathers of PyG gcn_norm (GCNConv, src/models.py:419), the
+ * remove_self_loops + add_self_loops of GATConv (src/models.py:425,135) and the in-degree count of
+ * SimpleConv(aggr="mean") (src/models.py:414).
+ * ------------------------------------------------------------------------------------------- */
+#define GCL_GRAPH_GCN 0  /* drop self-loops, append one per node, w_e = deg_in[s]^-1/2 * deg_in[r]^-1/2 */
+#define GCL_GRAPH_GAT 1  /* drop self-loops, append one per node, no weights */
+#define GCL_GRAPH_MEAN 2 /* edges as given, w_e = 1 / max(1, deg_in[r]) */
+
+/* Sizes of the processed edge set for (edge_index, E, n, kind): E' written to *e_out. */
+int gcl_graph_count_edges(const int64_t* edge_index, int64_t E, int32_t n, int32_t kind, int64_t* e_out);
+
+/* Host-only CSR construction into caller arrays (no GPU needed; used by gcl_graph_create and by
+ * the CPU tests).  edge_index is int64 [2,E] row 0 = sender, row 1 = receiver (src/models.py:12).
+ * Outputs (E' = gcl_graph_count_edges):
+ *   rowptr[n+1], col[E'] (sender of each slot), w[E'], eperm[E'] (slot -> position in the PyG edge
+ *   order "kept edges in input order, then loops 0..n-1"), and the transpose trowptr[n+1],
+ *   tcol[E'] (receiver), tw[E'], tslot[E'] (transpose slot -> forward slot).
+ * Within a row, slots keep PyG edge order (stable sort), so sums run in the reference's order. */
+int gcl_graph_build_host(const int64_t* edge_index, int64_t E, int32_t n, int32_t kind,
+                         int32_t* rowptr, int32_t* col, float* w, int32_t* eperm,
+                         int32_t* trowptr, int32_t* tcol, float* tw, int32_t* tslot);
+
+int gcl_graph_create(const int64_t* edge_index, int64_t E, int32_t n, int32_t kind, gcl_graph_t** out);
+void gcl_graph_destroy(gcl_graph_t* g);
+int32_t gcl_graph_num_nodes(const gcl_graph_t* g);
+int64_t gcl_graph_num_edges(const gcl_graph_t* g); /* E' */
+int32_t gcl_graph_max_in_degree(const gcl_graph_t* g);
+/* PyG-order edge list with loops, host int64 [2,E'] (what GATConv returns: src/models.py:135). */
+int gcl_graph_export_edges(const gcl_graph_t* g, int64_t* edge_index_out);
+/* Device pointer to eperm (int32 [E']), for callers that re-order per-slot data themselves. */
+const int32_t* gcl_graph_eperm_device(const gcl_graph_t* g);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense per-node transform  y = act(x) W^T (+ bias)      [rows, Fin] x [Fout, Fin]^T
+ * Replaces nn.Linear (+ the preceding nn.PReLU) inside MLP.forward (src/models.py:106-109) and the
+ * `lin` GEMM inside every GCNConv/GATConv (src/models.py:419,425).  fp32 in, fp32 accumulate
+ * (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain in k order).
+ * ------------------------------------------------------------------------------------------- */
+int gcl_linear_fwd(const float* x, int64_t ldx, const float* in_slope, const float* W /*[Fout,Fin]*/,
+                   const float* bias /*[Fout] or NULL*/, float* y, int64_t ldy, int64_t rows,
+                   int32_t Fin, int32_t Fout, gcl_stream_t stream);
+
+/* dx = (dy W) * PReLU'(x)   [rows, Fin]; adds sum(dy W * min(0,x)) into *d_in_slope when in_slope
+ * is given.  ws: gcl_linear_bwd_ws_bytes(rows, Fin, Fout). */
+int gcl_linear_bwd_dx(const float* dy, int64_t lddy, const float* W, const float* x, int64_t ldx,
+                      const float* in_slope, float* d_in_slope, float* dx, int64_t lddx,
+                      int64_t rows, int32_t Fin, int32_t Fout, void* ws, size_t ws_bytes,
+                      gcl_stream_t stream);
+/* dW (+)= dy^T act(x), db (+)= colsum(dy) (db may be NULL).  accumulate != 0 adds into dW/db. */
+int gcl_linear_bwd_dw(const float* dy, int64_t lddy, const float* x, int64_t ldx,
+                      const float* in_slope, float* dW, float* db, int64_t rows, int32_t Fin,
+                      int32_t Fout, int32_t accumulate, void* ws, size_t ws_bytes,
+                      gcl_stream_t stream);
+size_t gcl_linear_bwd_ws_bytes(int64_t rows, int32_t Fin, int32_t Fout);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sparse aggregation over the CSR  y[b,i,:] = sum_{e in row i} w_e * h[b, col_e, :] (+ bias)
+ * Replaces the index_select -> multiply -> scatter_add_ of PyG propagate for GCNConv
+ * (src/models.py:419) and SimpleConv mean (src/models.py:414).  transpose != 0 walks the
+ * sender-sorted CSR instead (the backward: dh = A_hat^T dy).
+ * ------------------------------------------------------------------------------------------- */
+int gcl_aggregate(const gcl_graph_t* g, int32_t transpose, const float* h, int64_t ldh, int64_t bsh,
+                  const float* bias, float* y, int64_t ldy, int64_t bsy, int32_t B, int32_t F,
+                  gcl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GATConv(heads=H, concat=False) attention + aggregation  (src/models.py:425; SparseGATConv :135)
+ *   a_s = <h, att_src>, a_d = <h, att_dst> per head; e = LeakyReLU_0.2(a_s[j] + a_d[i]);
+ *   softmax over the in-edges of i (max subtracted, +1e-16 in the denominator);
+ *   y[i] = mean_heads sum_e alpha_e h[j_e] + bias.
+ * h is the output of gcl_linear_fwd with Fout = H*C, laid out [B, n, H*C].
+ * alpha (may be NULL in inference) is written per CSR slot: [B, E', H].
+ * ------------------------------------------------------------------------------------------- */
+int gcl_gat_fwd(const gcl_graph_t* g, const float* h, int64_t ldh, int64_t bsh,
+                const float* att_src /*[H*C]*/, const float* att_dst /*[H*C]*/, const float* bias /*[C]*/,
+                float* a_src /*[B,n,H]*/, float* a_dst /*[B,n,H]*/, float* alpha /*[B,E',H]*/,
+                float* y, int64_t ldy, int64_t bsy, int32_t B, int32_t H, int32_t C,
+                gcl_stream_t stream);
+/* Gradients of gcl_gat_fwd: dh [B,n,H*C] (grad of the linear output, attention paths included),
+ * d_att_src/d_att_dst [H*C] and d_bias [C] (added when accumulate != 0, else overwritten).
+ * ws: gcl_gat_bwd_ws_bytes(E', n, B, H, C). */
+int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, int64_t bsdy,
+                const float* h, int64_t ldh, int64_t bsh, const float* att_src, const float* att_dst,
+                const float* a_src, const float* a_dst, const float* alpha,
+                float* dh, int64_t lddh, int64_t bsdh, float* d_att_src, float* d_att_dst,
+                float* d_bias, int32_t accumulate, int32_t B, int32_t H, int32_t C,
+                void* ws, size_t ws_bytes, gcl_stream_t stream);
+size_t gcl_gat_bwd_ws_bytes(int64_t e_prime, int32_t n, int32_t B, int32_t H, int32_t C);
+/* Re-order per-slot attention of ONE sample into PyG edge order: out[eperm[s]*H + k] = alpha[s*H + k]
+ * (what SparseGATConv thresholds: src/models.py:136-149). */
+int gcl_gat_alpha_to_edge_order(const gcl_graph_t* g, const float* alpha_slots, float* alpha_edges,
+                                int32_t H, gcl_stream_t stream);
+/* SparseGATConv prune (src/models.py:138-149): keep PyG-order edges with alpha >= threshold.
+ * alpha_edges is a DEVICE array [E'] (H = 1).  Writes the surviving edge list, host int64
+ * [2, *kept] (capacity E'), synchronising `stream` once.  Wave-ballot + prefix compaction. */
+int gcl_gat_prune(const gcl_graph_t* g, const float* alpha_edges, float threshold,
+                  int64_t* edge_index_out, int64_t* kept, void* ws, size_t ws_bytes,
+                  gcl_stream_t stream);
+size_t gcl_gat_prune_ws_bytes(int64_t e_prime);
+
+/* ---------------------------------------------------------------------------------------------
+ * PyG LayerNorm(mode="node")  (src/models.py:102-104,368-374): per row, eps inside the sqrt.
+ * stats [rows,2] receives (mean, rstd) for the backward.  x may carry an activation (in_slope).
+ * ------------------------------------------------------------------------------------------- */
+int gcl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                      float* y, int64_t ldy, float* stats, int64_t rows, int32_t F,
+                      gcl_stream_t stream);
+int gcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                      const float* stats, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                      int32_t accumulate, int64_t rows, int32_t F, void* ws, size_t ws_bytes,
+                      gcl_stream_t stream);
+size_t gcl_layernorm_bwd_ws_bytes(int64_t rows, int32_t F);
+/* PyG LayerNorm(mode="graph"): statistics over all n*F elements of each sample, eps added to the
+ * std.  stats [B,2] = (mean, 1/(std+eps)). */
+int gcl_graphnorm_fwd(const float* x, int64_t ldx, int64_t bsx, const float* gamma, const float* beta,
+                      float eps, float* y, int64_t ldy, int64_t bsy, float* stats, int32_t B,
+                      int32_t n, int32_t F, void* ws, size_t ws_bytes, gcl_stream_t stream);
+int gcl_graphnorm_bwd(const float* dy, int64_t lddy, int64_t bsdy, const float* x, int64_t ldx,
+                      int64_t bsx, const float* gamma, const float* stats, float eps, float* dx,
+                      int64_t lddx, int64_t bsdx, float* dgamma, float* dbeta, int32_t accumulate,
+                      int32_t B, int32_t n, int32_t F, void* ws, size_t ws_bytes, gcl_stream_t stream);
+size_t gcl_graphnorm_ws_bytes(int32_t B, int32_t n, int32_t F);
+
+/* Column sums  out[c] (+)= sum_r x[r,c]  (bias gradients of the conv layers). */
+int gcl_colsum(const float* x, int64_t ldx, int64_t rows, int32_t F, float* out, int32_t accumulate,
+               void* ws, size_t ws_bytes, gcl_stream_t stream);
+size_t gcl_colsum_ws_bytes(int64_t rows, int32_t F);
+
+/* ---------------------------------------------------------------------------------------------
+ * Input assembly (src/models.py:776-806): out[b] = [ x[b] | grid_static ; 0 | mesh_static ],
+ * out is [B, G+M, Cdyn+Cs].  The reference re-allocates the zero block and re-concatenates on
+ * every forward.
+ * ------------------------------------------------------------------------------------------- */
+int gcl_assemble_input(const float* x /*[B,G,Cdyn]*/, const float* grid_static /*[G,Cs]*/,
+                       const float* mesh_static /*[M,Cs]*/, float* out, int64_t ldo, int32_t B,
+                       int32_t G, int32_t M, int32_t Cdyn, int32_t Cs, gcl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Residual add + weighted MSE and its gradient (src/train.py:203-213, 85-102).
+ *   out = x_last + delta (use_residual) or delta; loss = sum(w (out-y)^2) * inv_wsum;
+ *   w[g,c] = node_w[g] * chan_w[c] (either may be NULL = 1);
+ *   d_delta = 2 w (out-y) * inv_wsum * grad_scale.
+ * x_last / y are addressed as base + b*bs + g*ld + c.  loss_out: one device float (overwritten).
+ * out_state (may be NULL) receives `out` for autoregressive roll-forward.
+ * ------------------------------------------------------------------------------------------- */
+int gcl_wmse_fwd_bwd(const float* delta, int64_t ldd, int64_t bsd, const float* x_last, int64_t ldx,
+                     int64_t bsx, const float* y, int64_t ldy_, int64_t bsy, const float* node_w,
+                     const float* chan_w, float inv_wsum, float grad_scale, float* d_delta,
+                     float* out_state, float* loss_out, int32_t B, int32_t G, int32_t C,
+                     void* ws, size_t ws_bytes, gcl_stream_t stream);
+size_t gcl_wmse_ws_bytes(int32_t B, int32_t G, int32_t C);
+
+/* torch.optim.Adam step (src/main.py:212, src/train.py:233) over one flat parameter buffer:
+ * grad_scale multiplies the gradient first (1/world after the gradient all-reduce). */
+int gcl_adam_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
+                  gcl_stream_t stream);
+
+/* Strided row copy  dst[b, i, 0:F] = src[b, i, 0:F]  (stage glue: src/models.py:837-838,860-862). */
+int gcl_copy_rows(const float* src, int64_t lds, int64_t bss, float* dst, int64_t ldd, int64_t bsd,
+                  int32_t B, int32_t rows, int32_t F, gcl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCL_H */

@@ -1,0 +1,267 @@
+"""Per-kernel parity on the GPU: every C-ABI compute entry point against the CPU oracle
+(fp32, tolerance 1e-5 relative unless stated) on seeded inputs, including ragged / odd shapes."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import build_graphs, experiment
+from oracle import pyg_ops as P
+from oracle import train_step as T
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-5
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.fixture(scope="module")
+def hip(lib_built):
+    from graphcast_lite_amd import hip as H
+
+    return H
+
+
+@pytest.mark.parametrize("rows,Fin,Fout", [(1000, 72, 48), (4096, 64, 64), (257, 48, 33), (130, 44, 128),
+                                           (5, 19, 19), (3000, 128, 128), (128, 66, 64), (1, 64, 64)])
+@pytest.mark.parametrize("with_slope", [False, True])
+def test_linear_fwd(hip, rows, Fin, Fout, with_slope):
+    x, W, b = rnd(rows, Fin, seed=1), rnd(Fout, Fin, seed=2, scale=0.2), rnd(Fout, seed=3)
+    a = torch.tensor([0.25]) if with_slope else None
+    ref = (P.prelu(x, a) if with_slope else x) @ W.t() + b
+    y = hip.linear_fwd(x.to(DEV), W.to(DEV), b.to(DEV), a.to(DEV) if with_slope else None)
+    assert rel(y, ref) < TOL
+    y2 = hip.linear_fwd(x.to(DEV), W.to(DEV), None, None, ld_out=(Fout + 3) // 4 * 4)
+    assert rel(y2, x @ W.t()) < TOL
+
+
+@pytest.mark.parametrize("rows,Fin,Fout", [(1000, 72, 48), (4099, 64, 64), (300, 48, 33), (77, 44, 128), (2000, 128, 128)])
+def test_linear_bwd(hip, rows, Fin, Fout):
+    x = rnd(rows, Fin, seed=1).requires_grad_()
+    W = rnd(Fout, Fin, seed=2, scale=0.2).requires_grad_()
+    b = rnd(Fout, seed=3).requires_grad_()
+    a = torch.tensor([0.25], requires_grad=True)
+    dy = rnd(rows, Fout, seed=4)
+    (P.prelu(x, a) @ W.t() + b).backward(dy)
+    xd, Wd, ad, dyd = x.detach().to(DEV), W.detach().to(DEV), a.detach().to(DEV), dy.to(DEV)
+    da = torch.zeros(1, device=DEV)
+    dx = hip.linear_bwd_dx(dyd, Wd, xd, ad, da)
+    dW, db = torch.empty(Fout, Fin, device=DEV), torch.empty(Fout, device=DEV)
+    hip.linear_bwd_dw(dyd, xd, ad, dW, db, False)
+    assert rel(dx, x.grad) < TOL and rel(dW, W.grad) < TOL and rel(db, b.grad) < TOL
+    assert rel(da, a.grad) < 1e-4
+    # accumulate flag adds on top
+    hip.linear_bwd_dw(dyd, xd, ad, dW, db, True)
+    assert rel(dW, 2 * W.grad) < TOL and rel(db, 2 * b.grad) < TOL
+    # no activation on the input
+    dx2 = hip.linear_bwd_dx(dyd, Wd, None, None, None)
+    assert rel(dx2, dy @ W.detach()) < TOL
+
+
+def test_linear_mfma_equals_valu(hip, monkeypatch):
+    """The fp32 MFMA path and the plain VALU path of the same entry point agree (both fp32 FMA chains)."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from graphcast_lite_amd import hip\n"
+        "g = torch.Generator().manual_seed(5)\n"
+        "x = torch.randn(777, 72, generator=g).cuda(); W = (torch.randn(48, 72, generator=g) * 0.2).cuda()\n"
+        "y = hip.linear_fwd(x, W, None, None)\n"
+        "torch.save(y.cpu(), sys.argv[1])\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for impl in ("mfma", "valu"):
+        path = f"/tmp/gcl_lin_{impl}.pt"
+        env = dict(os.environ, GCL_LINEAR_IMPL=impl)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env)
+        outs.append(torch.load(path))
+    assert rel(outs[0], outs[1]) < 2e-6
+
+
+@pytest.mark.parametrize("levels,F,B", [([1, 2], 64, 3), ([1, 2], 33, 2), ([3, 5], 64, 9), ([1, 2], 128, 8),
+                                        ([0], 19, 1), ([1, 2], 48, 16), ([1, 2], 4, 2), ([1, 2], 132, 1)])
+def test_gcn_aggregate_mesh(hip, levels, F, B):
+    g = build_graphs(experiment("baseline", mesh_levels=levels))
+    n = g["M"]
+    h, b = rnd(B, n, F, seed=1), rnd(F, seed=2)
+    ei, w = P.gcn_norm(g["proc"], n, torch.float32)
+    ref = P._propagate_sum(h, ei, w, n) + b
+    G = hip.Graph(g["proc"], n, hip.GRAPH_GCN)
+    assert G.e == g["proc"].shape[1] + n
+    y = hip.aggregate(G, h.to(DEV), b.to(DEV))
+    assert rel(y, ref) < TOL
+    # transpose = gradient of the aggregation
+    dy = rnd(B, n, F, seed=3)
+    hr = h.clone().requires_grad_()
+    (P._propagate_sum(hr, ei, w, n)).backward(dy)
+    dh = hip.aggregate(G, dy.to(DEV), None, transpose=True)
+    assert rel(dh, hr.grad) < TOL
+
+
+def test_gcn_aggregate_bipartite_and_padded_ld(hip):
+    """Encoder (skewed in-degree, most rows self-loop only) and decoder graphs, padded scratch input."""
+    g = build_graphs(experiment("baseline", mesh_levels=[3, 5]))
+    n = g["G"] + g["M"]
+    for ei_ref in (g["enc"], g["dec"]):
+        G = hip.Graph(ei_ref, n, hip.GRAPH_GCN)
+        for F, ld in ((33, 36), (48, 48), (64, 64)):
+            B = 2
+            buf = rnd(B, n, ld, seed=F)
+            h = buf[..., :F]
+            ei, w = P.gcn_norm(ei_ref, n, torch.float32)
+            ref = P._propagate_sum(h, ei, w, n)
+            hd = buf.to(DEV)[..., :F]
+            y = hip.aggregate(G, hd, None)
+            assert rel(y, ref) < TOL
+
+
+def test_mean_aggregate(hip):
+    g = build_graphs(experiment("baseline", mesh_levels=[1, 2]))
+    n = g["G"] + g["M"]
+    x = rnd(2, n, 64, seed=4)
+    for ei in (g["enc"], g["dec"]):
+        G = hip.Graph(ei, n, hip.GRAPH_MEAN)
+        y = hip.aggregate(G, x.to(DEV), None)
+        ref = P.simple_conv_mean(x, ei)
+        assert rel(y, ref) < TOL
+        assert (y.cpu()[ref == 0] == 0).all()  # nodes without in-edges are exactly zero
+
+
+@pytest.mark.parametrize("rows,F", [(1000, 64), (333, 128), (50, 33), (7, 12), (4096, 48)])
+def test_layernorm(hip, rows, F):
+    x = rnd(rows, F, seed=1).requires_grad_()
+    gm = (torch.rand(F, generator=torch.Generator().manual_seed(2)) + 0.5).requires_grad_()
+    bt = rnd(F, seed=3).requires_grad_()
+    dy = rnd(rows, F, seed=4)
+    ref = P.pyg_layer_norm(x, gm, bt, "node")
+    ref.backward(dy)
+    y, stats = hip.layernorm_fwd(x.detach().to(DEV), gm.detach().to(DEV), bt.detach().to(DEV))
+    assert rel(y, ref) < TOL
+    dg, db = torch.empty(F, device=DEV), torch.empty(F, device=DEV)
+    dx = hip.layernorm_bwd(dy.to(DEV), x.detach().to(DEV), gm.detach().to(DEV), stats, dg, db, False)
+    assert rel(dx, x.grad) < 2e-5 and rel(dg, gm.grad) < 2e-5 and rel(db, bt.grad) < TOL
+
+
+@pytest.mark.parametrize("rows,F", [(1000, 64), (13, 33), (5000, 128)])
+def test_colsum(hip, rows, F):
+    x = rnd(rows, F, seed=1)
+    out = torch.ones(F, device=DEV)
+    hip.colsum(x.to(DEV), out, True)
+    assert rel(out, x.sum(0) + 1) < TOL
+
+
+@pytest.mark.parametrize("levels,H,C,B", [([1, 2], 1, 64, 3), ([3, 5], 1, 64, 2), ([1, 2], 4, 64, 2), ([0], 2, 16, 1),
+                                          ([1, 2], 1, 128, 2)])
+def test_gat_fwd_bwd(hip, levels, H, C, B):
+    g = build_graphs(experiment("baseline", mesh_levels=levels))
+    n = g["M"]
+    Fin = 24
+    x = rnd(B, n, Fin, seed=1).requires_grad_()
+    W = rnd(H * C, Fin, seed=2, scale=0.3).requires_grad_()
+    a_s, a_d = rnd(1, H, C, seed=3, scale=0.3).requires_grad_(), rnd(1, H, C, seed=4, scale=0.3).requires_grad_()
+    b = rnd(C, seed=5).requires_grad_()
+    y_ref, ei2, alpha_ref = P.gat_conv(x, g["proc"], W, a_s, a_d, b, H)
+    dy = rnd(B, n, C, seed=6)
+    y_ref.backward(dy)
+    h_ref = (x.detach() @ W.detach().t())
+
+    G = hip.Graph(g["proc"], n, hip.GRAPH_GAT)
+    assert torch.equal(G.export_edges(), ei2)
+    hd = h_ref.to(DEV)
+    y, s_src, s_dst, alpha = hip.gat_fwd(G, hd, a_s.detach().reshape(-1).to(DEV), a_d.detach().reshape(-1).to(DEV),
+                                         b.detach().to(DEV), H, C)
+    assert rel(y, y_ref) < TOL
+    al_e = torch.stack([hip.gat_alpha_edge_order(G, alpha[i], H) for i in range(B)])
+    assert rel(al_e, alpha_ref) < TOL
+
+    d_as, d_ad, d_b = torch.empty(H * C, device=DEV), torch.empty(H * C, device=DEV), torch.empty(C, device=DEV)
+    dh = hip.gat_bwd(G, dy.to(DEV), hd, a_s.detach().reshape(-1).to(DEV), a_d.detach().reshape(-1).to(DEV), s_src,
+                     s_dst, alpha, d_as, d_ad, d_b, False, H, C)
+    # dh -> dW, dx through the dense transform (checked separately); compare dh via dW = dh^T x
+    dW = dh.reshape(-1, H * C).t().cpu() @ x.detach().reshape(-1, Fin)
+    assert rel(dW, W.grad) < 5e-5
+    assert rel(dh.cpu() @ W.detach(), x.grad) < 5e-5
+    assert rel(d_as.cpu(), a_s.grad.reshape(-1)) < 5e-5 and rel(d_ad.cpu(), a_d.grad.reshape(-1)) < 5e-5
+    assert rel(d_b, b.grad) < TOL
+
+
+def test_gat_unsupported_geometry_is_reported(hip):
+    g = build_graphs(experiment("baseline", mesh_levels=[0]))
+    G = hip.Graph(g["proc"], 12, hip.GRAPH_GAT)
+    h = torch.zeros(1, 12, 3 * 64, device=DEV)
+    z = torch.zeros(3 * 64, device=DEV)
+    with pytest.raises(RuntimeError, match="unsupported head geometry"):
+        hip.gat_fwd(G, h, z, z, torch.zeros(64, device=DEV), 3, 64)
+
+
+def test_gat_prune(hip):
+    g = build_graphs(experiment("baseline", mesh_levels=[1, 2]))
+    n = g["M"]
+    G = hip.Graph(g["proc"], n, hip.GRAPH_GAT)
+    alpha = torch.rand(G.e, generator=torch.Generator().manual_seed(3))
+    ei = G.export_edges()
+    for thr in (0.0, 0.3, 0.999, 2.0):
+        kept = hip.gat_prune(G, alpha.to(DEV), thr)
+        ref, _ = P.sparse_gat_prune(ei, alpha, thr)
+        assert torch.equal(kept, ref)
+    # a graph rebuilt from its own export keeps the tensor identity (no CSR rebuild per step)
+    ei_dev = ei.to(DEV)
+    G2 = hip.Graph(ei_dev, n, hip.GRAPH_GAT)
+    assert G2.edges_with_loops(ei_dev.device) is ei_dev
+
+
+def test_assemble_input(hip):
+    B, G, M, Cd, Cs = 3, 50, 20, 66, 6
+    x, gs, ms = rnd(B, G, Cd, seed=1), rnd(G, Cs, seed=2), rnd(M, Cs, seed=3)
+    out = hip.assemble_input(x.to(DEV), gs.to(DEV), ms.to(DEV)).cpu()
+    ref = torch.cat([torch.cat([x, gs.expand(B, G, Cs)], -1), torch.cat([torch.zeros(B, M, Cd), ms.expand(B, M, Cs)], -1)], 1)
+    assert torch.equal(out, ref)
+
+
+def test_weighted_mse(hip):
+    import os
+
+    from conftest import GOLDEN
+    from graphcast_lite_amd import train as TR
+
+    v = np.load(os.path.join(GOLDEN, "loss_vectors.npz"))
+    pred, target = torch.from_numpy(v["pred"]).to(DEV), torch.from_numpy(v["target"]).to(DEV)
+    lat, chan, sm = (torch.from_numpy(v[k]).to(DEV) for k in ("lat_w", "chan_mask", "spatial_mask"))
+    assert TR.weighted_mse_loss(pred, target).item() == pytest.approx(float(v["loss_plain"]), rel=1e-5)
+    assert TR.weighted_mse_loss(pred, target, lat).item() == pytest.approx(float(v["loss_lat"]), rel=1e-5)
+    assert TR.weighted_mse_loss(pred, target, lat, chan).item() == pytest.approx(float(v["loss_lat_chan"]), rel=1e-5)
+    assert TR.weighted_mse_loss(pred, target, lat, chan, sm).item() == pytest.approx(float(v["loss_all"]), rel=1e-5)
+    np.testing.assert_array_equal(TR.get_lat_weights(32, 64, "cpu").numpy(), v["lat_w"])
+    # gradient + residual add
+    p = torch.from_numpy(v["pred"]).requires_grad_()
+    xl = rnd(*p.shape, seed=9)
+    T.weighted_mse_loss(xl + p, torch.from_numpy(v["target"]), torch.from_numpy(v["lat_w"]),
+                        torch.from_numpy(v["chan_mask"])).backward()
+    pd = torch.from_numpy(v["pred"]).to(DEV).requires_grad_()
+    TR.weighted_mse_loss(pd, target, lat, chan, x_last=xl.to(DEV)).backward()
+    assert rel(pd.grad, p.grad) < TOL
+
+
+def test_adam_matches_torch(hip):
+    from graphcast_lite_amd import hip as H
+
+    p0, g = rnd(1000, seed=1), rnd(1000, seed=2)
+    pt = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([pt], lr=1e-3)
+    p, m, v = p0.to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for step in range(1, 6):
+        pt.grad = g * step
+        opt.step()
+        H.adam_step(p, (2 * g * step).to(DEV), m, v, 1e-3, 0.9, 0.999, 1e-8, 0.0, step, grad_scale=0.5)
+    assert rel(p, pt) < 1e-6
