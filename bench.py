@@ -1,0 +1,175 @@
+"""Headline benchmark: training samples/sec of the encode-process-decode GNN on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one optimiser step on a batch of synthetic 6-hour samples (forward, weighted-MSE
+loss with residual add, backward, gradient all-reduce when N > 1, Adam), batch fixed PER GPU
+(weak scaling).  Default workload = BASELINE.json configs[1]: Baseline GCN processor on
+wb2_64x32 (2048 grid nodes, 33 features, obs window 2, mesh levels [3,5]), 64 samples per GPU.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the mesh
+GCNConv aggregation kernel (HIP events on the launch stream, inside the timed region) and
+`cpu_baseline` = the CPU oracle (PyG op sequence, batch 1) timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4 copy is 6290
+
+
+def build_model(name, device, seed=42):
+    from graphcast_lite_amd.experiments import GRID, experiment
+    from graphcast_lite_amd.models import WeatherPrediction
+
+    cfg = experiment(name)
+    nlat, nlon = GRID[name]
+    lats = np.linspace(-90, 90, nlat, endpoint=True)
+    lons = np.linspace(0, 360, nlon, endpoint=False)
+    torch.manual_seed(seed)
+    return cfg, WeatherPrediction((lats, lons), cfg.graph, cfg.pipeline, cfg.data, device), (nlat, nlon)
+
+
+def synthetic_batch(cfg, G, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    F = cfg.data.num_features_used
+    X = torch.randn(B, G, cfg.data.obs_window_used * F, generator=g)
+    y = X[..., -F:] + 0.1 * torch.randn(B, G, F, generator=g)
+    return X, y
+
+
+def cpu_baseline(cfg, model, grid, budget_s=15.0, max_steps=30):
+    """The CPU oracle executing PyG's op sequence at batch 1: forward +
+    weighted MSE + backward + torch Adam, on all host cores of this box."""
+    from oracle import model as omodel
+    from oracle import train_step as ostep
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    o = omodel.WeatherPrediction(
+        cfg.pipeline, cfg.data, num_grid_nodes=model._num_grid_nodes, num_mesh_nodes=model._num_mesh_nodes,
+        encoding_graph=model.encoding_graph.cpu(), processing_graph=model.processing_graph.cpu(),
+        decoding_graph=model.decoding_graph.cpu(), init_grid_features=model.init_grid_features.cpu(),
+        init_mesh_features=model.init_mesh_features.cpu(),
+        processing_edge_features=model._processing_edge_features.cpu())
+    o.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    opt = torch.optim.Adam(o.parameters(), lr=1e-3)
+    X, y = synthetic_batch(cfg, model._num_grid_nodes, 1, seed=1234)
+    lw = ostep.get_lat_weights(*grid)
+
+    def one():
+        opt.zero_grad()
+        loss = ostep.train_step_loss(o, X, y, lat_weights=lw)
+        loss.backward()
+        opt.step()
+
+    for _ in range(2):
+        one()
+    n, t0 = 0, time.perf_counter()
+    while n < max_steps and (time.perf_counter() - t0) < budget_s:
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} optimiser steps at batch 1 (fwd+loss+bwd+Adam) of the same config, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=0, help="samples per GPU (default: 64 at 64x32, 8 at 512x256)")
+    ap.add_argument("--config", default="baseline",
+                    choices=["baseline", "attention", "attention_h4", "sparse_attention", "wb2_512x256_19f_ar"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from graphcast_lite_amd import hip, models
+    from graphcast_lite_amd.train import TrainStep, get_lat_weights
+
+    hip.lib()
+    cfg, model, grid = build_model(args.config, dev)
+    B = args.batch or (8 if args.config == "wb2_512x256_19f_ar" else 64)
+    G, M = model._num_grid_nodes, model._num_mesh_nodes
+    X, y = synthetic_batch(cfg, G, B, seed=1234 + rank)  # every rank its own samples
+    X, y = X.to(dev), y.to(dev)                           # resident in HBM before the timed region
+    step = TrainStep(model, lr=1e-3, lat_weights=get_lat_weights(grid[0], grid[1], dev), world_size=world)
+
+    for _ in range(args.warmup):
+        loss = step(X, y)
+    # time the mesh-processor aggregation launches (forward) inside the timed region
+    is_gcn = cfg.pipeline.processor.gcn.layer_type.value == "conv_gcn"
+    if is_gcn:
+        pg = models._graphs.get(model.processing_graph, M, hip.GRAPH_GCN)
+        hip.AGG_PROFILE = {"graph": pg, "events": []}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(X, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+
+    roof = None
+    if is_gcn and hip.AGG_PROFILE["events"]:
+        ev = hip.AGG_PROFILE["events"]
+        ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        F = cfg.pipeline.processor.gcn.output_dim
+        Ep = pg.e
+        per_sample = 4 * M * (F + F) + 4 * Ep + 4 * (M + 1) + 4 * M
+        achieved = B * per_sample / (ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "agg_kernel (mesh GCNConv aggregate, forward)", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_launch": B * per_sample, "avg_launch_us": ms * 1e3, "launches_timed": len(ev)}
+    hip.AGG_PROFILE = None
+
+    if rank == 0:
+        out = {
+            "metric": "training samples/sec (6h windows) + achieved HBM GB/s on mesh GCNConv",
+            "value": args.gpus * B * args.steps / dt, "unit": "samples/s", "n_gpus": args.gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config} (BASELINE.json configs[1] family): grid {grid[1]}x{grid[0]}, "
+                                   f"G={G}, mesh M={M}, {cfg.data.num_features_used} feat, obs 2, AR 1, "
+                                   f"fwd+loss+bwd+Adam", "batch_per_gpu": B, "global_batch": B * args.gpus,
+                       "parallelism": f"dp{args.gpus}", "final_loss": final_loss},
+            "roofline": roof,
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, model, grid)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

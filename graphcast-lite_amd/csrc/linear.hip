@@ -32,7 +32,7 @@ enum { EPI_BIAS = 0, EPI_DX = 1 };
 // panel is staged once per block into LDS with an odd row stride (conflict-free ds_read_b32 for the
 // 32-lanes-same-k fragment reads); every tile's rows are staged row-major the same way.
 // ---------------------------------------------------------------------------------------------
-template <int NS, int EPI>
+template <int NS, int EPI, int WAVES>
 __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restrict__ X, int64_t ldx,
                                                           const float* __restrict__ in_slope,
                                                           const float* __restrict__ W, int32_t ldw, int32_t trans,
@@ -40,16 +40,18 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
                                                           int64_t ldy, int64_t rows, int32_t K, int32_t N,
                                                           const float* __restrict__ Z, int64_t ldz,
                                                           const float* __restrict__ z_slope,
-                                                          float* __restrict__ slope_part, int32_t vec_x) {
+                                                          double* __restrict__ slope_part, int32_t vec_x) {
   extern __shared__ __align__(16) float smem[];
   const int KP = ((K + 1) & ~1) | 1;  // even K rounded up, then odd stride
   float* Wl = smem;                   // [NS*32][KP]
-  float* Xl = smem + (size_t)NS * 32 * KP;  // [4][32][KP]
+  float* Xl = smem + (size_t)NS * 32 * KP;  // [WAVES][32][KP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int KE = (K + 1) & ~1;
 
   // stage weights (zero-padded to NS*32 rows and KE columns)
-  for (int idx = tid; idx < NS * 32 * KE; idx += 256) {
+  constexpr int NT = WAVES * 64;
+  constexpr int TM = WAVES * 32;  // rows per tile
+  for (int idx = tid; idx < NS * 32 * KE; idx += NT) {
     const int j = idx / KE, k = idx - j * KE;
     float v = 0.f;
     if (j < N && k < K) v = trans ? W[(int64_t)k * ldw + j] : W[(int64_t)j * ldw + k];
@@ -58,12 +60,12 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
   const float slope = in_slope ? *in_slope : 1.f;
   const bool act = in_slope != nullptr;
   float* Xw = Xl + (size_t)wave * 32 * KP;
-  const int64_t ntiles = (rows + 127) / 128;
-  float slope_acc = 0.f;
+  const int64_t ntiles = (rows + TM - 1) / TM;
+  double slope_acc = 0.0;  // fp64: the slope gradient is a long signed sum with heavy cancellation
   const float zs = (EPI == EPI_DX && z_slope) ? *z_slope : 1.f;
 
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int64_t row0 = t * 128 + wave * 32;
+    const int64_t row0 = t * TM + wave * 32;
     __syncthreads();  // previous tile's fragment reads are done (also orders the Wl staging)
     if (vec_x) {
       const int nv = K >> 2;  // K % 4 == 0 on this path
@@ -87,7 +89,6 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
         Xw[r * KP + k] = v;
       }
     }
-    if (vec_x && (K & 1)) { /* unreachable: K%4==0 */ }
     __syncthreads();
 
     f32x16 acc[NS];
@@ -98,7 +99,6 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
 
     const float* ap = Xw + (lane & 31) * KP + (lane >> 5);
     const float* bp = Wl + (lane & 31) * KP + (lane >> 5);
-#pragma unroll 4
     for (int k0 = 0; k0 < KE; k0 += 2) {
       const float a = ap[k0];
 #pragma unroll
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
             } else if (Z) {
               const float z = Z[row * ldz + j];
               if (z <= 0.f) {
-                slope_acc += v * z;
+                slope_acc += (double)(v * z);
                 v *= zs;
               }
             }
@@ -136,12 +136,17 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
   }
 
   if (EPI == EPI_DX && slope_part) {
-    // block reduction of the slope gradient: wave shuffle, then LDS across the 4 waves
+    // block reduction of the slope gradient: wave shuffle, then LDS across the waves
     for (int off = 32; off > 0; off >>= 1) slope_acc += __shfl_down(slope_acc, off, 64);
     __syncthreads();
-    if (lane == 0) smem[wave] = slope_acc;
+    double* dred = reinterpret_cast<double*>(smem);
+    if (lane == 0) dred[wave] = slope_acc;
     __syncthreads();
-    if (tid == 0) slope_part[blockIdx.x] = smem[0] + smem[1] + smem[2] + smem[3];
+    if (tid == 0) {
+      double tot = 0.0;
+      for (int wv = 0; wv < WAVES; ++wv) tot += dred[wv];
+      slope_part[blockIdx.x] = tot;
+    }
   }
 }
 
@@ -154,12 +159,12 @@ __global__ __launch_bounds__(256) void linear_valu_kernel(const float* __restric
                                                           int64_t ldy, int64_t rows, int32_t K, int32_t N,
                                                           const float* __restrict__ Z, int64_t ldz,
                                                           const float* __restrict__ z_slope,
-                                                          float* __restrict__ slope_part) {
-  __shared__ float red[4];
+                                                          double* __restrict__ slope_part) {
+  __shared__ double red[4];
   const float slope = in_slope ? *in_slope : 1.f;
   const bool act = in_slope != nullptr;
   const float zs = (EPI == EPI_DX && z_slope) ? *z_slope : 1.f;
-  float slope_acc = 0.f;
+  double slope_acc = 0.0;
   const int64_t total = rows * N;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int64_t r = idx / N;
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256) void linear_valu_kernel(const float* __restric
     } else if (Z) {
       const float z = Z[r * ldz + j];
       if (z <= 0.f) {
-        slope_acc += acc * z;
+        slope_acc += (double)(acc * z);
         acc *= zs;
       }
     }
@@ -269,12 +274,12 @@ __global__ __launch_bounds__(256) void reduce_tiles_kernel(const float* __restri
   *o = accumulate ? *o + s : s;
 }
 
-__global__ void reduce_scalar_kernel(const float* __restrict__ part, int32_t nparts, float* __restrict__ out) {
+__global__ void reduce_scalar_kernel(const double* __restrict__ part, int32_t nparts, float* __restrict__ out) {
   // single wave; fixed order => deterministic
-  float s = 0.f;
+  double s = 0.0;
   for (int p = threadIdx.x; p < nparts; p += 64) s += part[p];
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if (threadIdx.x == 0) *out += s;
+  if (threadIdx.x == 0) *out += (float)s;
 }
 
 bool use_valu() {
@@ -291,17 +296,23 @@ constexpr int kDwBlocks = 256;
 
 struct LinGeom {
   int NS;
+  int waves;
   size_t lds;
   int grid;
 };
 
 int lin_geom(int64_t rows, int K, int N, LinGeom* g) {
-  GCL_CHECK_ARG(K >= 1 && K <= 256 && N >= 1 && N <= 128, "linear: unsupported K=%d N=%d (K<=256, N<=128)", K, N);
+  GCL_CHECK_ARG(K >= 1 && K <= 256 && N >= 1 && N <= 256, "linear: unsupported K=%d N=%d (K<=256, N<=256)", K, N);
   g->NS = (N + 31) / 32;
   const int KP = ((K + 1) & ~1) | 1;
+  g->waves = 4;
   g->lds = ((size_t)g->NS * 32 + 128) * KP * sizeof(float);
+  if (g->lds > 160 * 1024) {  // wide panels: 64-row tiles (2 waves) keep the weight panel resident
+    g->waves = 2;
+    g->lds = ((size_t)g->NS * 32 + 64) * KP * sizeof(float);
+  }
   GCL_CHECK_ARG(g->lds <= 160 * 1024, "linear: K=%d N=%d needs %zu B of LDS (>160 KiB)", K, N, g->lds);
-  const int64_t ntiles = (rows + 127) / 128;
+  const int64_t ntiles = gcl::cdiv(rows, 32 * g->waves);
   g->grid = (int)(ntiles < kMaxPersistentBlocks ? ntiles : kMaxPersistentBlocks);
   return GCL_OK;
 }
@@ -309,7 +320,7 @@ int lin_geom(int64_t rows, int K, int N, LinGeom* g) {
 template <int EPI>
 int launch_linear(const float* X, int64_t ldx, const float* in_slope, const float* W, int ldw, int trans,
                   const float* bias, float* Y, int64_t ldy, int64_t rows, int K, int N, const float* Z, int64_t ldz,
-                  const float* z_slope, float* slope_part, int* nparts, hipStream_t st) {
+                  const float* z_slope, double* slope_part, int* nparts, hipStream_t st) {
   if (rows == 0) {
     if (nparts) *nparts = 0;
     return GCL_OK;
@@ -327,20 +338,30 @@ int launch_linear(const float* X, int64_t ldx, const float* in_slope, const floa
   int rc = lin_geom(rows, K, N, &g);
   if (rc) return rc;
   const int vec_x = (K % 4 == 0) && (ldx % 4 == 0) && gcl::aligned16(X);
-#define GCL_LIN(NS_)                                                                                              \
+#define GCL_LIN2(NS_, W_)                                                                                         \
   do {                                                                                                            \
-    auto kern = linear_mfma_kernel<NS_, EPI>;                                                                     \
+    auto kern = linear_mfma_kernel<NS_, EPI, W_>;                                                                 \
     if (g.lds > 64 * 1024)                                                                                        \
       GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds)); \
-    hipLaunchKernelGGL(kern, dim3(g.grid), dim3(256), g.lds, st, X, ldx, in_slope, W, ldw, trans, bias, Y, ldy,   \
-                       rows, K, N, Z, ldz, z_slope, slope_part, vec_x);                                           \
+    hipLaunchKernelGGL(kern, dim3(g.grid), dim3(W_ * 64), g.lds, st, X, ldx, in_slope, W, ldw, trans, bias, Y,    \
+                       ldy, rows, K, N, Z, ldz, z_slope, slope_part, vec_x);                                      \
+  } while (0)
+#define GCL_LIN(NS_)                 \
+  do {                               \
+    if (g.waves == 4) GCL_LIN2(NS_, 4); \
+    else GCL_LIN2(NS_, 2);           \
   } while (0)
   switch (g.NS) {
     case 1: GCL_LIN(1); break;
     case 2: GCL_LIN(2); break;
     case 3: GCL_LIN(3); break;
-    default: GCL_LIN(4); break;
+    case 4: GCL_LIN(4); break;
+    case 5: GCL_LIN(5); break;
+    case 6: GCL_LIN(6); break;
+    case 7: GCL_LIN(7); break;
+    default: GCL_LIN(8); break;
   }
+#undef GCL_LIN2
 #undef GCL_LIN
   GCL_CHECK_LAUNCH();
   if (nparts) *nparts = g.grid;
@@ -361,7 +382,7 @@ extern "C" int gcl_linear_fwd(const float* x, int64_t ldx, const float* in_slope
 extern "C" size_t gcl_linear_bwd_ws_bytes(int64_t rows, int32_t Fin, int32_t Fout) {
   const size_t FinP = (size_t)((Fin + 31) / 32) * 32, FoutP = (size_t)((Fout + 31) / 32) * 32;
   const size_t dw = (size_t)kDwBlocks * FoutP * (FinP + 1) * sizeof(float);
-  const size_t sl = (size_t)4096 * sizeof(float);
+  const size_t sl = (size_t)4096 * sizeof(double);
   (void)rows;
   return dw + sl;
 }
@@ -373,10 +394,10 @@ extern "C" int gcl_linear_bwd_dx(const float* dy, int64_t lddy, const float* W, 
   GCL_CHECK_ARG(lddy >= Fout && lddx >= Fin, "linear_bwd_dx: leading dimension too small");
   GCL_CHECK_ARG(!in_slope || (x && ldx >= Fin), "linear_bwd_dx: in_slope given without the forward input x");
   hipStream_t st = (hipStream_t)stream;
-  float* slope_part = nullptr;
+  double* slope_part = nullptr;
   if (in_slope && d_in_slope) {
-    GCL_CHECK_ARG(ws && ws_bytes >= 4096 * sizeof(float), "linear_bwd_dx: workspace too small");
-    slope_part = (float*)ws;
+    GCL_CHECK_ARG(ws && ws_bytes >= 4096 * sizeof(double) && gcl::aligned16(ws), "linear_bwd_dx: workspace too small");
+    slope_part = (double*)ws;
   }
   int nparts = 0;
   // contraction over Fout: "weights" are W^T, i.e. Wl[j=c][k=o] = W[o*Fin + c]
@@ -395,7 +416,7 @@ extern "C" int gcl_linear_bwd_dw(const float* dy, int64_t lddy, const float* x, 
                                  void* ws, size_t ws_bytes, gcl_stream_t stream) {
   GCL_CHECK_ARG(dy && x && dW, "linear_bwd_dw: null argument");
   GCL_CHECK_ARG(lddy >= Fout && ldx >= Fin, "linear_bwd_dw: leading dimension too small");
-  GCL_CHECK_ARG(Fin >= 1 && Fin <= 128 && Fout >= 1 && Fout <= 128, "linear_bwd_dw: unsupported Fin=%d Fout=%d", Fin, Fout);
+  GCL_CHECK_ARG(Fin >= 1 && Fin <= 128 && Fout >= 1 && Fout <= 256, "linear_bwd_dw: unsupported Fin=%d Fout=%d (Fin<=128, Fout<=256)", Fin, Fout);
   GCL_CHECK_ARG(ws && ws_bytes >= gcl_linear_bwd_ws_bytes(rows, Fin, Fout), "linear_bwd_dw: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int NC = (Fin + 31) / 32, NO = (Fout + 31) / 32;

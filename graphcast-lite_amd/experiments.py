@@ -1,0 +1,47 @@
+"""The experiment configurations BASELINE.json names, restated as `ExperimentConfig` objects.
+
+Values are those of the reference's `experiments/{baseline,attention,sparse_attention,
+wb2_512x256_19f_ar}/config.json` (checked against `tests/golden/config_parse.json`, which was
+produced by parsing the reference's files with the reference's own pydantic schema)."""
+from .config import ExperimentConfig
+
+
+def _pipeline(enc_hidden, F, proc_type, proc_hidden, dec_mlp_hidden, dec_mlp_out, dec_hidden, out_dim, heads=1,
+              enc_dec_type="conv_gcn"):
+    gat = {"num_heads": heads, "sparsity_thresholds": [0.0, 0.0]}
+    return {
+        "encoder": {"mlp": {"mlp_hidden_dims": enc_hidden, "output_dim": F, "use_layer_norm": True,
+                            "layer_norm_mode": "node"},
+                    "gcn": {"layer_type": enc_dec_type, "hidden_dims": [F, F], "output_dim": F}},
+        "processor": {"gcn": {"layer_type": proc_type, "gat_props": gat, "hidden_dims": proc_hidden,
+                              "output_dim": F, "use_layer_norm": True, "layer_norm_mode": "node"}},
+        "decoder": {"mlp": {"mlp_hidden_dims": dec_mlp_hidden, "output_dim": dec_mlp_out, "use_layer_norm": False},
+                    "gcn": {"layer_type": enc_dec_type, "hidden_dims": dec_hidden, "output_dim": out_dim}},
+    }
+
+
+GRID = {"baseline": (32, 64), "attention": (32, 64), "attention_h4": (32, 64), "sparse_attention": (32, 64),
+        "wb2_512x256_19f_ar": (256, 512)}
+
+
+def experiment(name: str, mesh_levels=None) -> ExperimentConfig:
+    graph = {"grid2mesh_edge_creation": "radius", "mesh2grid_edge_creation": "contained",
+             "grid2mesh_radius_query": 0.5, "mesh_levels": mesh_levels or [3, 5]}
+    data = {"dataset_name": "synthetic", "num_features_used": 33, "obs_window_used": 2, "pred_window_used": 1,
+            "want_feats_flattened": True}
+    if name == "baseline":
+        pipe = _pipeline([48, 48], 64, "conv_gcn", [64, 64], [64, 64], 64, [48, 48], 33)
+    elif name == "attention":
+        pipe = _pipeline([48, 48], 64, "conv_gat", [64, 64], [64, 64], 64, [48, 48], 33)
+    elif name == "attention_h4":  # README.md:148-150 also reports 4 heads
+        pipe = _pipeline([48, 48], 64, "conv_gat", [64, 64], [64, 64], 64, [48, 48], 33, heads=4)
+    elif name == "sparse_attention":
+        pipe = _pipeline([48, 48], 64, "sparse_gat", [], [64, 64], 12, [48, 48], 12, enc_dec_type="simple_conv")
+        data.update(num_features_used=12)
+    elif name == "wb2_512x256_19f_ar":
+        pipe = _pipeline([128, 128], 128, "conv_gcn", [128] * 4, [128, 64], 64, [64, 64], 19)
+        graph.update(grid2mesh_radius_query=0.6, mesh_levels=mesh_levels or [4, 6])
+        data.update(num_features_used=19)
+    else:
+        raise KeyError(name)
+    return ExperimentConfig(graph=graph, pipeline=pipe, data=data)

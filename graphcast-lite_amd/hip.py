@@ -230,6 +230,11 @@ def linear_bwd_dw(dy, x, in_slope, dW, db, accumulate: bool):
                                    1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()))
 
 
+# bench.py sets this to {"graph": Graph, "events": []} to time the forward aggregation launches of
+# one graph with HIP events recorded on the launch stream (BENCH roofline line).
+AGG_PROFILE = None
+
+
 def aggregate(graph: Graph, h3, bias, transpose=False, out=None):
     """h3: [B, n, F] with unit channel stride; returns [B, n, F]."""
     B, n, F = h3.shape
@@ -237,8 +242,15 @@ def aggregate(graph: Graph, h3, bias, transpose=False, out=None):
     assert h3.stride(2) == 1
     if out is None:
         out = torch.empty(B, n, F, dtype=torch.float32, device=h3.device)
+    prof = AGG_PROFILE is not None and AGG_PROFILE["graph"] is graph and not transpose
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _check(lib().gcl_aggregate(graph.handle, 1 if transpose else 0, _p(h3), h3.stride(1), h3.stride(0), _p(bias),
                                _p(out), out.stride(1), out.stride(0), B, F, _stream()))
+    if prof:
+        e1.record()
+        AGG_PROFILE["events"].append((e0, e1))
     return out
 
 

@@ -37,45 +37,10 @@ def lib_built():
     return hip.lib()
 
 
-# experiment configurations named by BASELINE.json, restated as plain dicts (values taken from the
-# reference's experiments/*/config.json; checked against tests/golden/config_parse.json)
-def _pipeline(enc_hidden, enc_out, F, proc_type, proc_hidden, dec_mlp_hidden, dec_mlp_out, dec_hidden, out_dim,
-              heads=1, enc_dec_type="conv_gcn"):
-    gat = {"num_heads": heads, "sparsity_thresholds": [0.0, 0.0]}
-    return {
-        "encoder": {"mlp": {"mlp_hidden_dims": enc_hidden, "output_dim": enc_out, "use_layer_norm": True,
-                            "layer_norm_mode": "node"},
-                    "gcn": {"layer_type": enc_dec_type, "hidden_dims": [F, F], "output_dim": F}},
-        "processor": {"gcn": {"layer_type": proc_type, "gat_props": gat, "hidden_dims": proc_hidden,
-                              "output_dim": F, "use_layer_norm": True, "layer_norm_mode": "node"}},
-        "decoder": {"mlp": {"mlp_hidden_dims": dec_mlp_hidden, "output_dim": dec_mlp_out, "use_layer_norm": False},
-                    "gcn": {"layer_type": enc_dec_type, "hidden_dims": dec_hidden, "output_dim": out_dim}},
-    }
-
-
 def experiment(name: str, mesh_levels=None):
-    from graphcast_lite_amd.config import ExperimentConfig
+    from graphcast_lite_amd.experiments import experiment as _e
 
-    graph = {"grid2mesh_edge_creation": "radius", "mesh2grid_edge_creation": "contained",
-             "grid2mesh_radius_query": 0.5, "mesh_levels": mesh_levels or [3, 5]}
-    data = {"dataset_name": "synthetic", "num_features_used": 33, "obs_window_used": 2, "pred_window_used": 1,
-            "want_feats_flattened": True}
-    if name == "baseline":
-        pipe = _pipeline([48, 48], 64, 64, "conv_gcn", [64, 64], [64, 64], 64, [48, 48], 33)
-    elif name == "attention":
-        pipe = _pipeline([48, 48], 64, 64, "conv_gat", [64, 64], [64, 64], 64, [48, 48], 33)
-    elif name == "attention_h4":
-        pipe = _pipeline([48, 48], 64, 64, "conv_gat", [64, 64], [64, 64], 64, [48, 48], 33, heads=4)
-    elif name == "sparse_attention":
-        pipe = _pipeline([48, 48], 64, 64, "sparse_gat", [], [64, 64], 12, [48, 48], 12, enc_dec_type="simple_conv")
-        data.update(num_features_used=12)
-    elif name == "wb2_512x256_19f_ar":
-        pipe = _pipeline([128, 128], 128, 128, "conv_gcn", [128] * 4, [128, 64], 64, [64, 64], 19)
-        graph.update(grid2mesh_radius_query=0.6, mesh_levels=mesh_levels or [4, 6])
-        data.update(num_features_used=19)
-    else:
-        raise KeyError(name)
-    return ExperimentConfig(graph=graph, pipeline=pipe, data=data)
+    return _e(name, mesh_levels)
 
 
 def build_graphs(cfg, nlat=32, nlon=64):

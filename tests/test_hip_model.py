@@ -69,13 +69,19 @@ def test_forward_backward_parity(name, levels, B):
     loss_h = batch_loss(m, X.to(DEV), y.to(DEV), lat_weights=get_lat_weights(32, 64, DEV))
     loss_h.backward()
     assert rel(loss_h, loss_o) < 1e-5
+    # Gradients: 1e-4 relative per parameter, plus a floor of 1e-6 of the GLOBAL gradient norm.
+    # The floor is needed because some gradients are structurally ~0 (e.g. GAT att_dst when all
+    # pre-activations of a node's in-edges share a sign: 5e-19 in an fp64 run of the oracle), so
+    # both fp32 implementations only hold rounding noise there.
     og = dict(o.named_parameters())
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in og.values() if p.grad is not None)))
     for n_, p in m.named_parameters():
         if og[n_].grad is None:
             assert p.grad is None or float(p.grad.abs().sum()) == 0.0, n_
             continue
-        e = rel(p.grad, og[n_].grad)
-        assert e < 1e-4, f"{name}: gradient of {n_} rel err {e:.3e}"
+        d = float((p.grad.double().cpu() - og[n_].grad.double()).norm())
+        bound = 1e-4 * float(og[n_].grad.double().norm()) + 1e-6 * gn
+        assert d <= bound, f"{name}: gradient of {n_}: |diff| {d:.3e} > {bound:.3e}"
 
 
 def test_batch_one_follows_reference_squeeze():
