@@ -53,7 +53,13 @@ def cpu_baseline(cfg, model, grid, budget_s=15.0, max_steps=30):
     from oracle import model as omodel
     from oracle import train_step as ostep
 
-    cores = os.cpu_count() or 1
+    # threads actually available to this process (the GPU box gives a 1-GPU job a 16-CPU share;
+    # os.cpu_count() reports the whole host and oversubscribing it is >100x slower)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     o = omodel.WeatherPrediction(
         cfg.pipeline, cfg.data, num_grid_nodes=model._num_grid_nodes, num_mesh_nodes=model._num_mesh_nodes,

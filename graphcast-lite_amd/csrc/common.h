@@ -46,6 +46,10 @@ constexpr int kNumCU = 256;
 
 __device__ __forceinline__ float prelu_f(float x, float a) { return x > 0.f ? x : a * x; }
 
+// out[i*ldo + j] (+)= sum_p part[p*pstride + i*pld + j], i < R, j < C (parallel over partials, fixed order)
+int launch_reduce_parts(const float* part, int nparts, int64_t pstride, int pld, float* out, int ldo, int R, int C,
+                        int accumulate, hipStream_t st);
+
 }  // namespace gcl
 
 // Device-side graph arrays (owned by the handle).

@@ -265,16 +265,6 @@ __global__ __launch_bounds__(256) void gat_datt_kernel(const float* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int32_t nparts,
-                                                           int32_t pstride, float* __restrict__ out, int32_t count,
-                                                           int32_t accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= count) return;
-  float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * pstride + c];
-  out[c] = accumulate ? out[c] + s : s;
-}
-
 __global__ __launch_bounds__(256) void alpha_reorder_kernel(const int32_t* __restrict__ eperm,
                                                             const float* __restrict__ a_slots,
                                                             float* __restrict__ a_edges, int64_t Ep, int32_t H) {
@@ -356,7 +346,7 @@ extern "C" int gcl_gat_fwd(const gcl_graph_t* g, const float* h, int64_t ldh, in
 extern "C" size_t gcl_gat_bwd_ws_bytes(int64_t e_prime, int32_t n, int32_t B, int32_t H, int32_t C) {
   const size_t de = (size_t)B * e_prime * H;
   const size_t nodes = (size_t)B * n * H * 2;  // da_d, da_s
-  const size_t parts = (size_t)kGatBlocks * 2 * H * C + (size_t)1024 * C;
+  const size_t parts = (size_t)kGatBlocks * 2 * H * C + (size_t)1024 * C;  // + colsum scratch
   return (de + nodes + parts) * sizeof(float) + 256;
 }
 
@@ -409,11 +399,10 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
 #undef CALL
   GCL_CHECK_LAUNCH();
   const int HC = H * C;
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)gcl::cdiv(HC, 256)), dim3(256), 0, st, part, (int)nbd, 2 * HC,
-                     d_att_src, HC, accumulate);
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)gcl::cdiv(HC, 256)), dim3(256), 0, st, part + HC, (int)nbd,
-                     2 * HC, d_att_dst, HC, accumulate);
-  GCL_CHECK_LAUNCH();
+  rc = gcl::launch_reduce_parts(part, (int)nbd, 2 * HC, 2 * HC, d_att_src, HC, 1, HC, accumulate, st);
+  if (rc) return rc;
+  rc = gcl::launch_reduce_parts(part + HC, (int)nbd, 2 * HC, 2 * HC, d_att_dst, HC, 1, HC, accumulate, st);
+  if (rc) return rc;
   if (d_bias) {
     // dy rows are contiguous across the batch (checked above): one flat column sum
     rc = gcl_colsum(dy, lddy, rows, C, d_bias, accumulate, cs_ws, gcl_colsum_ws_bytes(rows, C), stream);

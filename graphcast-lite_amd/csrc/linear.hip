@@ -24,33 +24,70 @@ __device__ __forceinline__ int d_row(int reg, int lane) { return (reg & 3) + 8 *
 
 enum { EPI_BIAS = 0, EPI_DX = 1 };
 
+// Raw buffer access (hardware range check): loads beyond num_records return 0, stores are dropped.
+// Keeping every global access UNCONDITIONAL keeps the kernels free of divergent branches, which is
+// what lets hipcc emit counted s_waitcnt vmcnt(N) (CDNA counts loads and stores in one in-order
+// counter; a branch around a store forces vmcnt(0) and serialises the whole store stream).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB = 0x80000000u;  // offset that is out of range for every descriptor we build
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int64_t nbytes) {
+  const int64_t cap = 0x7FFFFF00;
+  const int n = (int)(nbytes < 0 ? 0 : (nbytes > cap ? cap : nbytes));
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+  return make_float4(__builtin_bit_cast(float, v.x), __builtin_bit_cast(float, v.y), __builtin_bit_cast(float, v.z),
+                     __builtin_bit_cast(float, v.w));
+}
+__device__ __forceinline__ void buf_st1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+// Zero page for masked loads: an out-of-range lane reads from here instead of branching around
+// its load (pointer select + unconditional plain load keeps global_load_dwordx4 and no branch).
+__device__ float4 gcl_zero4[1];
+
+// bytes of a [nrows x F] window with row stride ld (last row counted only up to F)
+__device__ __forceinline__ int64_t win_bytes(int64_t nrows, int64_t ld, int F) {
+  return nrows > 0 ? ((nrows - 1) * ld + F) * 4 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Y[r, j] = sum_k act(X[r,k]) * Wl[j,k]   with Wl[j,k] = TRANS ? W[k*ldw + j] : W[j*ldw + k]
 //   EPI_BIAS: + bias[j]
 //   EPI_DX  : * PReLU'(Z[r,j]) and the per-block sum of value*min(0,Z) goes to slope_part[block]
-// Block = 4 waves, each wave owns 32 rows of a 128-row tile; persistent over tiles.  The weight
+// Block = blockDim.x/64 waves, each wave owns 32 rows of a tile; persistent over tiles.  The weight
 // panel is staged once per block into LDS with an odd row stride (conflict-free ds_read_b32 for the
-// 32-lanes-same-k fragment reads); every tile's rows are staged row-major the same way.
+// 32-lanes-same-k fragment reads).  Row tiles are software-pipelined through registers: the global
+// loads of tile t+1 are issued before the MFMA loop of tile t and committed to LDS (with the
+// activation applied) after it, so HBM latency hides under the matrix work instead of being paid
+// once per tile.  KT = compile-time bound on K (size of the prefetch register array).
 // ---------------------------------------------------------------------------------------------
-template <int NS, int EPI, int WAVES>
-__global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restrict__ X, int64_t ldx,
+// waves per SIMD the register allocator must leave room for (LDS admits ~3 blocks of 4 waves at
+// K,N <= 64; wide panels are LDS-limited to 1-2 blocks anyway)
+constexpr int lin_min_waves(int NS, int KT) { return (NS <= 2 && KT <= 64) ? 3 : (NS <= 4 && KT <= 128) ? 2 : 1; }
+
+template <int NS, int EPI, int KT, bool VEC>
+__global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel(const float* __restrict__ X, int64_t ldx,
                                                           const float* __restrict__ in_slope,
                                                           const float* __restrict__ W, int32_t ldw, int32_t trans,
                                                           const float* __restrict__ bias, float* __restrict__ Y,
                                                           int64_t ldy, int64_t rows, int32_t K, int32_t N,
                                                           const float* __restrict__ Z, int64_t ldz,
                                                           const float* __restrict__ z_slope,
-                                                          double* __restrict__ slope_part, int32_t vec_x) {
+                                                          double* __restrict__ slope_part) {
   extern __shared__ __align__(16) float smem[];
-  const int KP = ((K + 1) & ~1) | 1;  // even K rounded up, then odd stride
+  const int KE = (K + 3) & ~3;        // K padded to a multiple of 4 (two MFMA k-steps per 8-B read)
+  const int KP = KE + 2;              // even stride with KP/2 odd: conflict-free ds_read_b64 fragments
   float* Wl = smem;                   // [NS*32][KP]
-  float* Xl = smem + (size_t)NS * 32 * KP;  // [WAVES][32][KP]
+  float* Xl = smem + (size_t)NS * 32 * KP;  // [waves][32][KP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int KE = (K + 1) & ~1;
+  const int NT = blockDim.x;
+  const int TM = (NT >> 6) * 32;  // rows per tile
 
-  // stage weights (zero-padded to NS*32 rows and KE columns)
-  constexpr int NT = WAVES * 64;
-  constexpr int TM = WAVES * 32;  // rows per tile
   for (int idx = tid; idx < NS * 32 * KE; idx += NT) {
     const int j = idx / KE, k = idx - j * KE;
     float v = 0.f;
@@ -64,32 +101,76 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
   double slope_acc = 0.0;  // fp64: the slope gradient is a long signed sum with heavy cancellation
   const float zs = (EPI == EPI_DX && z_slope) ? *z_slope : 1.f;
 
-  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int64_t row0 = t * TM + wave * 32;
-    __syncthreads();  // previous tile's fragment reads are done (also orders the Wl staging)
-    if (vec_x) {
-      const int nv = K >> 2;  // K % 4 == 0 on this path
-      for (int idx = lane; idx < 32 * nv; idx += 64) {
-        const int r = idx / nv, c4 = (idx - r * nv) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + r < rows) v = *reinterpret_cast<const float4*>(X + (row0 + r) * ldx + c4);
-        if (act) {
-          v.x = gcl::prelu_f(v.x, slope); v.y = gcl::prelu_f(v.y, slope);
-          v.z = gcl::prelu_f(v.z, slope); v.w = gcl::prelu_f(v.w, slope);
-        }
-        float* d = Xw + r * KP + c4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-      }
-    } else {
-      for (int idx = lane; idx < 32 * KE; idx += 64) {
-        const int r = idx / KE, k = idx - r * KE;
-        float v = 0.f;
-        if (row0 + r < rows && k < K) v = X[(row0 + r) * ldx + k];
-        if (act) v = gcl::prelu_f(v, slope);
-        Xw[r * KP + k] = v;
+  // Staging map of a wave's 32 x K tile (no divisions).  VEC: a row is KT/4 float4 columns, a
+  // wave-instruction covers 64/(KT/4) rows; scalar: a row is KT columns, KT/64 instructions per row.
+  constexpr int CPR = VEC ? KT / 4 : KT;                  // columns (float4 or float) per row slot
+  constexpr int RPI = CPR >= 64 ? 1 : 64 / CPR;           // rows per wave-instruction
+  constexpr int IPR = CPR >= 64 ? CPR / 64 : 1;           // instructions per row
+  constexpr int NIT = (32 / RPI) * IPR;                   // wave-instructions per tile
+  const int rsub = (CPR >= 64) ? 0 : lane / CPR;
+  const int csub = (CPR >= 64) ? lane : lane % CPR;
+  float pre[VEC ? NIT * 4 : NIT];
+  // per-lane constant parts of the staging offsets (bytes); masked columns point out of range
+  auto issue = [&](int64_t tile) {  // rows past the end (and tiles past the last) read the zero page
+    const int64_t r0 = tile * TM + wave * 32;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int64_t row = r0 + (it / IPR) * RPI + rsub;
+      const int c = csub + 64 * (it % IPR);
+      if (VEC) {
+        const bool ok = (c * 4 < K) && (row < rows);
+        const float4* p = ok ? reinterpret_cast<const float4*>(X + row * ldx + c * 4) : gcl_zero4;
+        const float4 v = *p;
+        pre[4 * it] = v.x; pre[4 * it + 1] = v.y; pre[4 * it + 2] = v.z; pre[4 * it + 3] = v.w;
+      } else {
+        const bool ok = (c < K) && (row < rows);
+        const float* p = ok ? X + row * ldx + c : reinterpret_cast<const float*>(gcl_zero4);
+        pre[it] = *p;
       }
     }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int r = (it / IPR) * RPI + rsub;
+      const int c = csub + 64 * (it % IPR);
+      if (VEC) {
+        if (c * 4 < KE) {
+          float2* d = reinterpret_cast<float2*>(Xw + r * KP + c * 4);
+          float v0 = pre[4 * it], v1 = pre[4 * it + 1], v2 = pre[4 * it + 2], v3 = pre[4 * it + 3];
+          if (act) {
+            v0 = gcl::prelu_f(v0, slope); v1 = gcl::prelu_f(v1, slope);
+            v2 = gcl::prelu_f(v2, slope); v3 = gcl::prelu_f(v3, slope);
+          }
+          d[0] = make_float2(v0, v1);
+          d[1] = make_float2(v2, v3);
+        }
+      } else {
+        if (c < KE) Xw[r * KP + c] = act ? gcl::prelu_f(pre[it], slope) : pre[it];  // zero beyond K
+      }
+    }
+  };
+
+  // bias of this lane's columns (loaded once, outside the tile loop)
+  float bj[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int j = s * 32 + (lane & 31);
+    bj[s] = (EPI == EPI_BIAS && bias && j < N) ? bias[j] : 0.f;
+  }
+  const bool has_z = (EPI == EPI_DX) && (Z != nullptr);
+
+  issue(blockIdx.x);
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    __syncthreads();  // previous tile's fragment reads are done (also orders the Wl staging)
+    commit();
     __syncthreads();
+    issue(t + gridDim.x);  // unconditional: an empty window past the last tile returns zeros
+
+    const int64_t r0 = t * TM;
+    const int64_t nr = (rows - r0) < TM ? (rows - r0) : TM;
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(Y + r0 * ldy, win_bytes(nr, ldy, N));
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(has_z ? Z + r0 * ldz : Y, has_z ? win_bytes(nr, ldz, N) : 0);
 
     f32x16 acc[NS];
 #pragma unroll
@@ -97,46 +178,65 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
 
-    const float* ap = Xw + (lane & 31) * KP + (lane >> 5);
-    const float* bp = Wl + (lane & 31) * KP + (lane >> 5);
-    for (int k0 = 0; k0 < KE; k0 += 2) {
-      const float a = ap[k0];
+    // k-step pair q covers k = 4q..4q+3: lane half h reads the 8 bytes k = 4q+2h, 4q+2h+1 and
+    // feeds .x to the first MFMA (k = 4q | 4q+2) and .y to the second (k = 4q+1 | 4q+3); A and B
+    // use the same assignment.  Fragments of pair q+1 are read before the MFMAs of pair q issue.
+    const float* ap = Xw + (lane & 31) * KP + 2 * (lane >> 5);
+    const float* bp = Wl + (lane & 31) * KP + 2 * (lane >> 5);
+    const int nq = KE >> 2;
+    float2 a_c = *reinterpret_cast<const float2*>(ap);
+    float2 b_c[NS];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const float bv = bp[s * 32 * KP + k0];
-        acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[s], 0, 0, 0);
-      }
+    for (int s = 0; s < NS; ++s) b_c[s] = *reinterpret_cast<const float2*>(bp + s * 32 * KP);
+    for (int q = 0; q < nq; ++q) {
+      // reads one pair ahead; the last iteration re-reads pair nq-1 (in range, unused)
+      const int qn = (q + 1 < nq) ? q + 1 : q;
+      const float2 a_n = *reinterpret_cast<const float2*>(ap + qn * 4);
+      float2 b_n[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) b_n[s] = *reinterpret_cast<const float2*>(bp + s * 32 * KP + qn * 4);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c.x, b_c[s].x, acc[s], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c.y, b_c[s].y, acc[s], 0, 0, 0);
+      a_c = a_n;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) b_c[s] = b_n[s];
     }
 
-    // epilogue: lane owns column j = s*32 + (lane&31), 16 rows
+    // epilogue: lane owns column j = s*32 + (lane&31) and 16 rows; all accesses unconditional
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int j = s * 32 + (lane & 31);
-      if (j < N) {
-        const float bj = (EPI == EPI_BIAS && bias) ? bias[j] : 0.f;
+      const bool jok = j < N;
+      if (EPI == EPI_DX) {
+        float zv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int64_t row = row0 + d_row(r, lane);
-          if (row < rows) {
-            float v = acc[s][r];
-            if (EPI == EPI_BIAS) {
-              v += bj;
-            } else if (Z) {
-              const float z = Z[row * ldz + j];
-              if (z <= 0.f) {
-                slope_acc += (double)(v * z);
-                v *= zs;
-              }
-            }
-            Y[row * ldy + j] = v;
+          const int rr = wave * 32 + d_row(r, lane);
+          zv[r] = buf_ld1(rz, jok ? (unsigned)((rr * ldz + j) * 4) : kOOB);  // 0 when absent / out of range
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = wave * 32 + d_row(r, lane);
+          float v = acc[s][r];
+          if (has_z && zv[r] <= 0.f) {
+            slope_acc += (double)(v * zv[r]);
+            v *= zs;
           }
+          buf_st1(ry, jok ? (unsigned)((rr * ldy + j) * 4) : kOOB, v);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = wave * 32 + d_row(r, lane);
+          buf_st1(ry, jok ? (unsigned)((rr * ldy + j) * 4) : kOOB, acc[s][r] + bj[s]);
         }
       }
     }
   }
 
   if (EPI == EPI_DX && slope_part) {
-    // block reduction of the slope gradient: wave shuffle, then LDS across the waves
     for (int off = 32; off > 0; off >>= 1) slope_acc += __shfl_down(slope_acc, off, 64);
     __syncthreads();
     double* dred = reinterpret_cast<double*>(smem);
@@ -144,7 +244,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
     __syncthreads();
     if (tid == 0) {
       double tot = 0.0;
-      for (int wv = 0; wv < WAVES; ++wv) tot += dred[wv];
+      for (int wv = 0; wv < (NT >> 6); ++wv) tot += dred[wv];
       slope_part[blockIdx.x] = tot;
     }
   }
@@ -196,82 +296,187 @@ __global__ __launch_bounds__(256) void linear_valu_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// dW partials:  P[chunk][o][c] = sum_{r in chunk} dY[r,o] * act(X[r,c])   (+ db partials)
-// A = dY^T and B = act(X) fragments come straight from global memory (lanes 0-31 read 128
-// contiguous bytes of row r, lanes 32-63 of row r+1), no LDS staging.  blockIdx.y = 32-wide slab of
-// output channels; each wave accumulates NC slabs of input channels over its rows, the 4 waves are
-// summed through LDS, one partial tile per block.
+// dW partials:  P[block][o][c] = sum_{r in block's rows} dY[r,o] * act(X[r,c])   (+ db partials)
+// A tall-skinny contraction over rows.  Each block walks its row range in 64-row steps: the dY and
+// act(X) rows of a step are fetched with 16-B loads into registers one step ahead (software
+// pipeline), committed to LDS, and the 4 waves run v_mfma_f32_32x32x2_f32 with A = dY^T and B = X
+// fragments read from LDS (lanes 0-31 read 32 consecutive channels of row k, lanes 32-63 of row
+// k+1: conflict-free).  The 32x32 output tiles are split over the waves as a WO x WC grid; wave
+// (wo,wc) owns o-slabs {wo, wo+WO, ..} x c-slabs {wc, wc+WC, ..} (TO x TC accumulators), so no
+// cross-wave reduction is needed.  One partial tile set per block, reduced by reduce_parts_kernel.
 // ---------------------------------------------------------------------------------------------
-template <int NC>
-__global__ __launch_bounds__(256) void dw_mfma_kernel(const float* __restrict__ dY, int64_t lddy,
-                                                      const float* __restrict__ X, int64_t ldx,
-                                                      const float* __restrict__ in_slope, float* __restrict__ part,
-                                                      float* __restrict__ dbpart, int64_t rows, int32_t Fin,
-                                                      int32_t Fout, int64_t rows_per_block, int32_t FinP,
-                                                      int32_t FoutP) {
-  extern __shared__ __align__(16) float smem[];  // [4][NC][32*32] + [4][32]
+constexpr int kDwRT = 64;  // rows per step
+
+template <int NO, int NC>
+struct DwCfg {
+  static constexpr int WO = NO >= 4 ? 4 : NO;         // waves along the output-channel slabs
+  static constexpr int WC = 4 / WO;                   // waves along the input-channel slabs
+  static constexpr int TO = NO / WO;                  // o-slabs per wave
+  static constexpr int TC = (NC + WC - 1) / WC;       // c-slabs per wave
+  static constexpr int PRE = 2 * (NO + NC);           // float4 staging registers per thread
+  static constexpr int FoutP = NO * 32, FinP = NC * 32;
+  static constexpr int min_waves = (PRE <= 8 && TO * TC <= 2) ? 3 : (PRE <= 16 && TO * TC <= 4) ? 2 : 1;
+};
+
+template <int NO, int NC, bool VEC>
+__global__ __launch_bounds__(256, (DwCfg<NO, NC>::min_waves)) void dw_mfma_kernel(
+    const float* __restrict__ dY, int64_t lddy, const float* __restrict__ X, int64_t ldx,
+    const float* __restrict__ in_slope, float* __restrict__ part, float* __restrict__ dbpart, int64_t rows,
+    int32_t Fin, int32_t Fout, int64_t rows_per_block) {
+  using Cfg = DwCfg<NO, NC>;
+  constexpr int WO = Cfg::WO, WC = Cfg::WC, TO = Cfg::TO, TC = Cfg::TC, PRE = Cfg::PRE;
+  constexpr int FoutP = Cfg::FoutP, FinP = Cfg::FinP;
+  extern __shared__ __align__(16) float smem[];
+  float* Yl = smem;                          // [kDwRT][FoutP]
+  float* Xl = smem + (size_t)kDwRT * FoutP;  // [kDwRT][FinP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int o0 = blockIdx.y * 32;
   const int li = lane & 31, lk = lane >> 5;
+  const int wo = wave % WO, wc = wave / WO;
   const float slope = in_slope ? *in_slope : 1.f;
   const bool act = in_slope != nullptr;
   const int64_t rb = (int64_t)blockIdx.x * rows_per_block;
   const int64_t re = min(rows, rb + rows_per_block);
+  const int nrows = (int)(re - rb);
 
-  f32x16 acc[NC];
+  f32x16 acc[TO][TC];
 #pragma unroll
-  for (int c = 0; c < NC; ++c)
+  for (int a = 0; a < TO; ++a)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-  float dbacc = 0.f;
-  const bool oact = (o0 + li) < Fout;
+    for (int c = 0; c < TC; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+  float dbacc[TO];
+#pragma unroll
+  for (int a = 0; a < TO; ++a) dbacc[a] = 0.f;
 
-  // waves interleave row pairs: wave w takes pairs w, w+4, ...
-  for (int64_t r = rb + 2 * wave; r < re; r += 8) {
-    const int64_t rr = r + lk;
-    const bool v = rr < re;
-    const float a = (v && oact) ? dY[rr * lddy + o0 + li] : 0.f;
-    dbacc += a;
+  // Staging map of a 64-row step (no divisions): thread = (row slot rs = tid/8, column group
+  // cg = tid%8); it owns rows rs and rs+32 and the float4 columns cg + 8*j of dY (j < NO) and of
+  // X (j < NC).  8 consecutive lanes read 128 contiguous bytes.  All loads are unconditional:
+  // rows past the block's range and columns past F read the zero page.
+  const int rs = tid >> 3, cg = tid & 7;
+  float4 pre[PRE];
+  const float* ybase = dY + rb * lddy;
+  const float* xbase = X + rb * ldx;
+  auto ld_slot = [&](const float* base, int rr, int c4, int64_t ld, int F) -> float4 {
+    const bool ok = rr < nrows;
+    const float* z = reinterpret_cast<const float*>(gcl_zero4);
+    const float* src = base + (int64_t)rr * ld + c4;
+    if (VEC) return *reinterpret_cast<const float4*>((ok && c4 < F) ? src : z);
+    float4 v;
+    v.x = *((ok && c4 < F) ? src : z);
+    v.y = *((ok && c4 + 1 < F) ? src + 1 : z);
+    v.z = *((ok && c4 + 2 < F) ? src + 2 : z);
+    v.w = *((ok && c4 + 3 < F) ? src + 3 : z);
+    return v;
+  };
+  auto issue = [&](int rel0) {
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int ch = c * 32 + li;
-      float bv = (v && ch < Fin) ? X[rr * ldx + ch] : 0.f;
-      if (act) bv = gcl::prelu_f(bv, slope);
-      acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[c], 0, 0, 0);
+    for (int it = 0; it < PRE; ++it) {
+      const int j = it >> 1;
+      const int rr = rel0 + rs + 32 * (it & 1);
+      if (j < NO) pre[it] = ld_slot(ybase, rr, (cg + 8 * j) * 4, lddy, Fout);
+      else pre[it] = ld_slot(xbase, rr, (cg + 8 * (j - NO)) * 4, ldx, Fin);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < PRE; ++it) {
+      const int j = it >> 1;
+      const int r = rs + 32 * (it & 1);
+      float4 v = pre[it];
+      if (j < NO) {
+        *reinterpret_cast<float4*>(Yl + r * FoutP + (cg + 8 * j) * 4) = v;
+      } else {
+        if (act) {
+          v.x = gcl::prelu_f(v.x, slope); v.y = gcl::prelu_f(v.y, slope);
+          v.z = gcl::prelu_f(v.z, slope); v.w = gcl::prelu_f(v.w, slope);
+        }
+        *reinterpret_cast<float4*>(Xl + r * FinP + (cg + 8 * (j - NO)) * 4) = v;
+      }
+    }
+  };
+
+  issue(0);
+  for (int rel0 = 0; rel0 < nrows; rel0 += kDwRT) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    issue(rel0 + kDwRT);  // unconditional (zeros past the end)
+    const float* yp = Yl + lk * FoutP + li;
+    const float* xp = Xl + lk * FinP + li;
+    float av[TO], bv[TC];
+#pragma unroll
+    for (int a = 0; a < TO; ++a) av[a] = yp[(wo + a * WO) * 32];
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+      const int sc = wc + c * WC;
+      bv[c] = (sc < NC) ? xp[sc * 32] : 0.f;
+    }
+    for (int k = 0; k < kDwRT; k += 2) {
+      // fragments of the next row pair, read before this pair's MFMAs issue (last: re-read)
+      const int kn = (k + 2 < kDwRT) ? k + 2 : k;
+      float an[TO], bn[TC];
+#pragma unroll
+      for (int a = 0; a < TO; ++a) an[a] = yp[kn * FoutP + (wo + a * WO) * 32];
+#pragma unroll
+      for (int c = 0; c < TC; ++c) {
+        const int sc = wc + c * WC;
+        bn[c] = (sc < NC) ? xp[kn * FinP + sc * 32] : 0.f;
+      }
+#pragma unroll
+      for (int a = 0; a < TO; ++a) {
+        dbacc[a] += av[a];
+#pragma unroll
+        for (int c = 0; c < TC; ++c)
+          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[c], acc[a][c], 0, 0, 0);
+      }
+#pragma unroll
+      for (int a = 0; a < TO; ++a) av[a] = an[a];
+#pragma unroll
+      for (int c = 0; c < TC; ++c) bv[c] = bn[c];
     }
   }
 
-  // cross-wave sum through LDS: tile element (i = out channel, j = in channel)
-  float* tile = smem + (size_t)wave * NC * 1024;
+  float* out = part + (size_t)blockIdx.x * FoutP * FinP;
 #pragma unroll
-  for (int c = 0; c < NC; ++c)
+  for (int a = 0; a < TO; ++a) {
+    const int so = wo + a * WO;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tile[c * 1024 + d_row(r, lane) * 32 + li] = acc[c][r];
-  dbacc += __shfl_xor(dbacc, 32, 64);
-  float* dbl = smem + (size_t)4 * NC * 1024;
-  if (lane < 32) dbl[wave * 32 + lane] = dbacc;
-  __syncthreads();
-  float* out = part + ((size_t)blockIdx.x * FoutP + o0) * FinP;
-  for (int idx = tid; idx < NC * 1024; idx += 256) {
-    const int c = idx >> 10, i = (idx >> 5) & 31, j = idx & 31;
-    const float s = smem[idx] + smem[NC * 1024 + idx] + smem[2 * NC * 1024 + idx] + smem[3 * NC * 1024 + idx];
-    out[(size_t)i * FinP + c * 32 + j] = s;
+    for (int c = 0; c < TC; ++c) {
+      const int sc = wc + c * WC;
+      if (sc < NC) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          out[(size_t)(so * 32 + d_row(r, lane)) * FinP + sc * 32 + li] = acc[a][c][r];
+      }
+    }
+    if (dbpart && wc == 0) {
+      const float d = dbacc[a] + __shfl_xor(dbacc[a], 32, 64);
+      if (lane < 32) dbpart[(size_t)blockIdx.x * FoutP + so * 32 + lane] = d;
+    }
   }
-  if (dbpart && tid < 32)
-    dbpart[(size_t)blockIdx.x * FoutP + o0 + tid] = dbl[tid] + dbl[32 + tid] + dbl[64 + tid] + dbl[96 + tid];
 }
 
-// out[i*ldo + j] (+)= sum_p part[p*pstride + i*FinP + j]   for i < R, j < C
-__global__ __launch_bounds__(256) void reduce_tiles_kernel(const float* __restrict__ part, int32_t nparts,
+// out[i*ldo + j] (+)= sum_p part[p*pstride + i*pld + j]   for i < R, j < C.
+// 64 outputs per block, 4 thread groups split the partials, combined through LDS (fixed order).
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int32_t nparts,
                                                            int64_t pstride, int32_t pld, float* __restrict__ out,
                                                            int32_t ldo, int32_t R, int32_t C, int32_t accumulate) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= R * C) return;
-  const int i = idx / C, j = idx - i * C;
+  __shared__ float red[4][64];
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + e;
+  const bool ok = idx < R * C;
+  const int i = ok ? idx / C : 0, j = ok ? idx - i * C : 0;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * pstride + (size_t)i * pld + j];
-  float* o = out + (size_t)i * ldo + j;
-  *o = accumulate ? *o + s : s;
+  if (ok)
+    for (int p = g; p < nparts; p += 4) s += part[(size_t)p * pstride + (size_t)i * pld + j];
+  red[g][e] = s;
+  __syncthreads();
+  if (g == 0 && ok) {
+    const float tot = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    float* o = out + (size_t)i * ldo + j;
+    *o = accumulate ? *o + tot : tot;
+  }
 }
 
 __global__ void reduce_scalar_kernel(const double* __restrict__ part, int32_t nparts, float* __restrict__ out) {
@@ -281,6 +486,20 @@ __global__ void reduce_scalar_kernel(const double* __restrict__ part, int32_t np
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if (threadIdx.x == 0) *out += (float)s;
 }
+
+}  // namespace
+
+namespace gcl {
+int launch_reduce_parts(const float* part, int nparts, int64_t pstride, int pld, float* out, int ldo, int R, int C,
+                        int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv((int64_t)R * C, 64)), dim3(256), 0, st, part, nparts,
+                     pstride, pld, out, ldo, R, C, accumulate);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+}  // namespace gcl
+
+namespace {
 
 bool use_valu() {
   static int v = -1;
@@ -292,28 +511,39 @@ bool use_valu() {
 }
 
 constexpr int kMaxPersistentBlocks = 1024;
-constexpr int kDwBlocks = 256;
+constexpr int kDwBlocks = 512;
 
 struct LinGeom {
   int NS;
   int waves;
+  int KT;
   size_t lds;
   int grid;
 };
 
-int lin_geom(int64_t rows, int K, int N, LinGeom* g) {
+int lin_geom(int64_t rows, int K, int N, bool vec_x, LinGeom* g) {
   GCL_CHECK_ARG(K >= 1 && K <= 256 && N >= 1 && N <= 256, "linear: unsupported K=%d N=%d (K<=256, N<=256)", K, N);
+  GCL_CHECK_ARG(vec_x || K <= 128, "linear: K=%d > 128 needs 16-B aligned rows (ld %% 4 == 0)", K);
   g->NS = (N + 31) / 32;
-  const int KP = ((K + 1) & ~1) | 1;
+  if (g->NS == 3) g->NS = 4;
+  if (g->NS > 4) g->NS = 8;  // instantiated: 1,2,4,8
+  g->KT = K <= 64 ? 64 : K <= 128 ? 128 : 256;
+  const int KP = ((K + 3) & ~3) + 2;
   g->waves = 4;
-  g->lds = ((size_t)g->NS * 32 + 128) * KP * sizeof(float);
+  g->lds = ((size_t)g->NS * 32 + 128) * KP * sizeof(float) + 64;
   if (g->lds > 160 * 1024) {  // wide panels: 64-row tiles (2 waves) keep the weight panel resident
     g->waves = 2;
-    g->lds = ((size_t)g->NS * 32 + 64) * KP * sizeof(float);
+    g->lds = ((size_t)g->NS * 32 + 64) * KP * sizeof(float) + 64;
   }
   GCL_CHECK_ARG(g->lds <= 160 * 1024, "linear: K=%d N=%d needs %zu B of LDS (>160 KiB)", K, N, g->lds);
+  // persistent grid = what is resident at once (LDS- and register-limited), so no partial last wave
+  int bpc = (int)((160 * 1024) / g->lds);
+  const int by_regs = lin_min_waves(g->NS, g->KT) * 4 / g->waves;
+  if (bpc > by_regs) bpc = by_regs;
+  if (bpc < 1) bpc = 1;
   const int64_t ntiles = gcl::cdiv(rows, 32 * g->waves);
-  g->grid = (int)(ntiles < kMaxPersistentBlocks ? ntiles : kMaxPersistentBlocks);
+  const int64_t cap = (int64_t)gcl::kNumCU * bpc;
+  g->grid = (int)(ntiles < cap ? ntiles : cap);
   return GCL_OK;
 }
 
@@ -334,35 +564,38 @@ int launch_linear(const float* X, int64_t ldx, const float* in_slope, const floa
     if (nparts) *nparts = grid;
     return GCL_OK;
   }
-  LinGeom g;
-  int rc = lin_geom(rows, K, N, &g);
-  if (rc) return rc;
   const int vec_x = (K % 4 == 0) && (ldx % 4 == 0) && gcl::aligned16(X);
-#define GCL_LIN2(NS_, W_)                                                                                         \
+  LinGeom g;
+  int rc = lin_geom(rows, K, N, vec_x != 0, &g);
+  if (rc) return rc;
+#define GCL_LIN3(NS_, KT_, V_)                                                                                    \
   do {                                                                                                            \
-    auto kern = linear_mfma_kernel<NS_, EPI, W_>;                                                                 \
+    auto kern = linear_mfma_kernel<NS_, EPI, KT_, V_>;                                                            \
     if (g.lds > 64 * 1024)                                                                                        \
       GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds)); \
-    hipLaunchKernelGGL(kern, dim3(g.grid), dim3(W_ * 64), g.lds, st, X, ldx, in_slope, W, ldw, trans, bias, Y,    \
-                       ldy, rows, K, N, Z, ldz, z_slope, slope_part, vec_x);                                      \
+    hipLaunchKernelGGL(kern, dim3(g.grid), dim3(g.waves * 64), g.lds, st, X, ldx, in_slope, W, ldw, trans, bias,  \
+                       Y, ldy, rows, K, N, Z, ldz, z_slope, slope_part);                                          \
   } while (0)
-#define GCL_LIN(NS_)                 \
-  do {                               \
-    if (g.waves == 4) GCL_LIN2(NS_, 4); \
-    else GCL_LIN2(NS_, 2);           \
+#define GCL_LIN2(NS_, KT_)                 \
+  do {                                     \
+    if (vec_x) GCL_LIN3(NS_, KT_, true);   \
+    else GCL_LIN3(NS_, KT_, false);        \
+  } while (0)
+#define GCL_LIN(NS_)                                \
+  do {                                              \
+    if (g.KT == 64) GCL_LIN2(NS_, 64);              \
+    else if (g.KT == 128) GCL_LIN2(NS_, 128);       \
+    else GCL_LIN3(NS_, 256, true);                  \
   } while (0)
   switch (g.NS) {
     case 1: GCL_LIN(1); break;
     case 2: GCL_LIN(2); break;
-    case 3: GCL_LIN(3); break;
     case 4: GCL_LIN(4); break;
-    case 5: GCL_LIN(5); break;
-    case 6: GCL_LIN(6); break;
-    case 7: GCL_LIN(7); break;
     default: GCL_LIN(8); break;
   }
-#undef GCL_LIN2
+#undef GCL_LIN3
 #undef GCL_LIN
+#undef GCL_LIN2
   GCL_CHECK_LAUNCH();
   if (nparts) *nparts = g.grid;
   return GCL_OK;
@@ -380,7 +613,10 @@ extern "C" int gcl_linear_fwd(const float* x, int64_t ldx, const float* in_slope
 }
 
 extern "C" size_t gcl_linear_bwd_ws_bytes(int64_t rows, int32_t Fin, int32_t Fout) {
-  const size_t FinP = (size_t)((Fin + 31) / 32) * 32, FoutP = (size_t)((Fout + 31) / 32) * 32;
+  const size_t FinP = (size_t)((Fin + 31) / 32) * 32;
+  size_t no = (size_t)(Fout + 31) / 32;
+  no = no <= 2 ? no : no <= 4 ? 4 : 8;
+  const size_t FoutP = no * 32;
   const size_t dw = (size_t)kDwBlocks * FoutP * (FinP + 1) * sizeof(float);
   const size_t sl = (size_t)4096 * sizeof(double);
   (void)rows;
@@ -416,41 +652,61 @@ extern "C" int gcl_linear_bwd_dw(const float* dy, int64_t lddy, const float* x, 
                                  void* ws, size_t ws_bytes, gcl_stream_t stream) {
   GCL_CHECK_ARG(dy && x && dW, "linear_bwd_dw: null argument");
   GCL_CHECK_ARG(lddy >= Fout && ldx >= Fin, "linear_bwd_dw: leading dimension too small");
-  GCL_CHECK_ARG(Fin >= 1 && Fin <= 128 && Fout >= 1 && Fout <= 256, "linear_bwd_dw: unsupported Fin=%d Fout=%d (Fin<=128, Fout<=256)", Fin, Fout);
+  GCL_CHECK_ARG(Fin >= 1 && Fin <= 128 && Fout >= 1 && Fout <= 256,
+                "linear_bwd_dw: unsupported Fin=%d Fout=%d (Fin<=128, Fout<=256)", Fin, Fout);
   GCL_CHECK_ARG(ws && ws_bytes >= gcl_linear_bwd_ws_bytes(rows, Fin, Fout), "linear_bwd_dw: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  const int NC = (Fin + 31) / 32, NO = (Fout + 31) / 32;
+  const int NC = (Fin + 31) / 32;
+  int NO = (Fout + 31) / 32;
+  NO = NO <= 2 ? NO : NO <= 4 ? 4 : 8;  // instantiated: 1, 2, 4, 8 (extra slabs are zero)
   const int FinP = NC * 32, FoutP = NO * 32;
-  int64_t nblk = gcl::cdiv(rows, 64);  // at least 64 rows per block
+  int64_t nblk = gcl::cdiv(rows, 2 * kDwRT);  // at least two steps per block
   if (nblk > kDwBlocks) nblk = kDwBlocks;
   if (nblk < 1) nblk = 1;
   int64_t rpb = gcl::cdiv(rows, nblk);
-  rpb = (rpb + 7) & ~(int64_t)7;  // whole 8-row wave rounds
+  rpb = gcl::cdiv(rpb, kDwRT) * kDwRT;
   nblk = rows > 0 ? gcl::cdiv(rows, rpb) : 1;
   float* part = (float*)ws;
   float* dbpart = part + (size_t)kDwBlocks * FoutP * FinP;
-  const size_t lds = ((size_t)4 * NC * 1024 + 128) * sizeof(float);
-#define GCL_DW(NC_)                                                                                               \
+  const size_t lds = (size_t)kDwRT * (FoutP + FinP) * sizeof(float);
+  const bool vec = (lddy % 4 == 0) && (ldx % 4 == 0) && gcl::aligned16(dy) && gcl::aligned16(x);
+#define GCL_DW3(NO_, NC_, V_)                                                                                     \
   do {                                                                                                            \
-    auto kern = dw_mfma_kernel<NC_>;                                                                              \
+    auto kern = dw_mfma_kernel<NO_, NC_, V_>;                                                                     \
     if (lds > 64 * 1024)                                                                                          \
       GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, NO), dim3(256), lds, st, dy, lddy, x, ldx, in_slope, part,      \
-                       db ? dbpart : nullptr, rows, Fin, Fout, rpb, FinP, FoutP);                                 \
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, dy, lddy, x, ldx, in_slope, part,          \
+                       db ? dbpart : nullptr, rows, Fin, Fout, rpb);                                              \
   } while (0)
-  switch (NC) {
+#define GCL_DW2(NO_, NC_)              \
+  do {                                 \
+    if (vec) GCL_DW3(NO_, NC_, true);  \
+    else GCL_DW3(NO_, NC_, false);     \
+  } while (0)
+#define GCL_DW(NO_)                    \
+  do {                                 \
+    switch (NC) {                      \
+      case 1: GCL_DW2(NO_, 1); break;  \
+      case 2: GCL_DW2(NO_, 2); break;  \
+      case 3: GCL_DW2(NO_, 3); break;  \
+      default: GCL_DW2(NO_, 4); break; \
+    }                                  \
+  } while (0)
+  switch (NO) {
     case 1: GCL_DW(1); break;
     case 2: GCL_DW(2); break;
-    case 3: GCL_DW(3); break;
-    default: GCL_DW(4); break;
+    case 4: GCL_DW(4); break;
+    default: GCL_DW(8); break;
   }
 #undef GCL_DW
+#undef GCL_DW2
+#undef GCL_DW3
   GCL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_tiles_kernel, dim3((unsigned)gcl::cdiv((int64_t)Fout * Fin, 256)), dim3(256), 0, st, part,
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)gcl::cdiv((int64_t)Fout * Fin, 64)), dim3(256), 0, st, part,
                      (int)nblk, (int64_t)FoutP * FinP, FinP, dW, Fin, Fout, Fin, accumulate);
   GCL_CHECK_LAUNCH();
   if (db) {
-    hipLaunchKernelGGL(reduce_tiles_kernel, dim3((unsigned)gcl::cdiv(Fout, 256)), dim3(256), 0, st, dbpart, (int)nblk,
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)gcl::cdiv(Fout, 64)), dim3(256), 0, st, dbpart, (int)nblk,
                        (int64_t)FoutP, FoutP, db, Fout, 1, Fout, accumulate);
     GCL_CHECK_LAUNCH();
   }

@@ -147,17 +147,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   }
 }
 
-__global__ __launch_bounds__(256) void reduce_cols_kernel(const float* __restrict__ part, int32_t nparts,
-                                                          int32_t pstride, float* __restrict__ out, int32_t count,
-                                                          int32_t accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= count) return;
-  float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * pstride + c];
-  out[c] = accumulate ? out[c] + s : s;
-}
-
-constexpr int kNormBlocks = 1024;
+constexpr int kNormBlocks = 512;
 
 inline int lpr_for(int F) {
   const int lanes = (F + 3) / 4;
@@ -224,12 +214,9 @@ extern "C" int gcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
   GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
   GCL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)gcl::cdiv(F, 256)), dim3(256), 0, st, part, (int)nb, 2 * FP,
-                     dgamma, F, accumulate);
-  hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)gcl::cdiv(F, 256)), dim3(256), 0, st, part + FP, (int)nb,
-                     2 * FP, dbeta, F, accumulate);
-  GCL_CHECK_LAUNCH();
-  return GCL_OK;
+  int rc = gcl::launch_reduce_parts(part, (int)nb, 2 * FP, 2 * FP, dgamma, F, 1, F, accumulate, st);
+  if (rc) return rc;
+  return gcl::launch_reduce_parts(part + FP, (int)nb, 2 * FP, 2 * FP, dbeta, F, 1, F, accumulate, st);
 }
 
 extern "C" size_t gcl_colsum_ws_bytes(int64_t rows, int32_t F) {
@@ -255,8 +242,5 @@ extern "C" int gcl_colsum(const float* x, int64_t ldx, int64_t rows, int32_t F, 
   GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
   GCL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)gcl::cdiv(F, 256)), dim3(256), 0, st, part, (int)nb, FP, out, F,
-                     accumulate);
-  GCL_CHECK_LAUNCH();
-  return GCL_OK;
+  return gcl::launch_reduce_parts(part, (int)nb, FP, FP, out, F, 1, F, accumulate, st);
 }

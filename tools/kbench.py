@@ -1,0 +1,108 @@
+"""Per-kernel micro-benchmark at the BASELINE.json shapes (HIP events, median of N launches).
+
+    python tools/kbench.py [--config baseline|wb2] [--iters 20]
+
+Prints for every C-ABI kernel on the training path: time, algorithmic GB/s and TFLOP/s, so a
+kernel can be read against its roofline (HBM 8 TB/s spec / 6.3 measured; fp32 MFMA 157 TFLOP/s).
+Development tool: not part of the product path, the tests or bench.py.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graphcast_lite_amd import hip  # noqa: E402
+from graphcast_lite_amd.experiments import GRID, experiment  # noqa: E402
+from graphcast_lite_amd.models import WeatherPrediction  # noqa: E402
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3)
+    return float(np.median(ts)), float(np.min(ts))
+
+
+def row(name, us, mn, bytes_, flops):
+    print(f"{name:44s} {us:9.1f} us (min {mn:8.1f})  {bytes_ / us / 1e3:8.1f} GB/s  {flops / us / 1e6:7.2f} TFLOP/s", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="baseline")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=0)
+    args = ap.parse_args()
+    name = "wb2_512x256_19f_ar" if args.config.startswith("wb2") else args.config
+    dev = torch.device("cuda:0")
+    cfg = experiment(name)
+    nlat, nlon = GRID[name]
+    m = WeatherPrediction((np.linspace(-90, 90, nlat), np.linspace(0, 360, nlon, endpoint=False)), cfg.graph,
+                          cfg.pipeline, cfg.data, dev)
+    B = args.batch or (8 if name.startswith("wb2") else 64)
+    G, M = m._num_grid_nodes, m._num_mesh_nodes
+    n = G + M
+    F = cfg.pipeline.processor.gcn.output_dim
+    print(f"# {name}: B={B} G={G} M={M} n={n} F={F}")
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+
+    # stream copy ceiling
+    src, dst = rnd(64 * 1024 * 1024), torch.empty(64 * 1024 * 1024, device=dev)
+    us, mn = timeit(lambda: dst.copy_(src), args.iters)
+    row("torch copy 256 MiB (read+write)", us, mn, 2 * src.numel() * 4, 0)
+
+    slope = torch.tensor([0.25], device=dev)
+    for rows, K, N, tag in ((B * n, F, F, "enc/dec"), (B * M, F, F, "mesh"), (B * n, cfg.data.num_features_used * 2 + 6, cfg.pipeline.encoder.mlp.mlp_hidden_dims[0], "mlp0")):
+        x, W, b = rnd(rows, K), rnd(N, K) * 0.1, rnd(N)
+        y = torch.empty(rows, N, device=dev)
+        us, mn = timeit(lambda: hip.linear_fwd(x, W, b, slope, out=y), args.iters)
+        row(f"linear_fwd {tag} [{rows}x{K}]->{N}", us, mn, 4 * rows * (K + N), 2 * rows * K * N)
+        dy = rnd(rows, N)
+        ds = torch.zeros(1, device=dev)
+        us, mn = timeit(lambda: hip.linear_bwd_dx(dy, W, x, slope, ds), args.iters)
+        row(f"linear_bwd_dx {tag} [{rows}x{N}]->{K}", us, mn, 4 * rows * (2 * K + N), 2 * rows * K * N)
+        dW, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+        us, mn = timeit(lambda: hip.linear_bwd_dw(dy, x, slope, dW, db, False), args.iters)
+        row(f"linear_bwd_dw {tag} [{rows}x{N}]^T[{rows}x{K}]", us, mn, 4 * rows * (K + N), 2 * rows * K * N)
+
+    from graphcast_lite_amd.models import _graphs
+    for ei, nn_, tag in ((m.processing_graph, M, "mesh E_M"), (m.encoding_graph, n, "enc E_G2M"), (m.decoding_graph, n, "dec E_M2G")):
+        gr = _graphs.get(ei, nn_, hip.GRAPH_GCN)
+        h, bias = rnd(B, nn_, F), rnd(F)
+        out = torch.empty(B, nn_, F, device=dev)
+        per = 4 * nn_ * 2 * F + 4 * gr.e + 4 * (nn_ + 1) + 4 * nn_
+        us, mn = timeit(lambda: hip.aggregate(gr, h, bias, out=out), args.iters)
+        row(f"aggregate fwd {tag} n={nn_} E'={gr.e} F={F}", us, mn, B * per, 2 * B * gr.e * F)
+        us, mn = timeit(lambda: hip.aggregate(gr, h, None, transpose=True, out=out), args.iters)
+        row(f"aggregate bwd {tag} (transpose)", us, mn, B * per, 2 * B * gr.e * F)
+
+    rows = B * n
+    x, gm, bt = rnd(rows, F), rnd(F), rnd(F)
+    us, mn = timeit(lambda: hip.layernorm_fwd(x, gm, bt), args.iters)
+    row(f"layernorm_fwd [{rows}x{F}]", us, mn, 4 * rows * 2 * F, 0)
+    y, st = hip.layernorm_fwd(x, gm, bt)
+    dg, dbt = torch.empty(F, device=dev), torch.empty(F, device=dev)
+    us, mn = timeit(lambda: hip.layernorm_bwd(x, x, gm, st, dg, dbt, False), args.iters)
+    row(f"layernorm_bwd [{rows}x{F}]", us, mn, 4 * rows * 3 * F, 0)
+    o = torch.empty(F, device=dev)
+    us, mn = timeit(lambda: hip.colsum(x, o, False), args.iters)
+    row(f"colsum [{rows}x{F}]", us, mn, 4 * rows * F, 0)
+    X = rnd(B, G, cfg.data.num_features_used * 2)
+    us, mn = timeit(lambda: hip.assemble_input(X, m.init_grid_features, m.init_mesh_features), args.iters)
+    row("assemble_input", us, mn, 4 * B * n * (X.shape[-1] + 6), 0)
+
+
+if __name__ == "__main__":
+    main()
