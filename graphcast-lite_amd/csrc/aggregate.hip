@@ -16,18 +16,27 @@
 // b&7 names an XCD group.  All row-blocks of sample s are given ids congruent to s mod 8: one
 // sample's h (2.6 MB at 64x32/F=64) then lives in ONE 4 MiB L2 and the ~7x neighbour re-reads
 // never leave the XCD.  Placement is a speed choice only; results do not depend on it.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
-template <int LPR, bool VL, bool VS>
+// EW = number of ELL-prefix neighbours every row reads unconditionally (1, 2, 4 or 8; chosen per
+// graph so that most rows fit).  Per batch the dependency chain is: {rowptr pair, ELL entries}
+// (one round trip, prefetched one batch ahead) -> EW neighbour rows issued together -> store.
+// Rows with more than EW in-edges finish in a CSR loop (wave-uniform test).  Padded slots load a
+// valid row and are masked with a select (not a multiply), so non-finite values cannot leak.
+template <int LPR, bool VL, bool VS, int EW, int ITER>
 __global__ __launch_bounds__(256) void agg_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                  const float* __restrict__ w, const float* __restrict__ H,
+                                                  const float* __restrict__ w, const int32_t* __restrict__ ecol,
+                                                  const float* __restrict__ ew, const float* __restrict__ H,
                                                   int64_t ldh, int64_t bsh, const float* __restrict__ bias,
                                                   float* __restrict__ Y, int64_t ldy, int64_t bsy, int32_t n,
                                                   int32_t B, int32_t F, int32_t nRB, int32_t xcd_map) {
   constexpr int RPW = 64 / LPR;
-  constexpr int RPB = RPW * 4;
+  constexpr int EL = LPR < gcl::kEll ? LPR : gcl::kEll;  // ELL entries a lane group can hold
+  static_assert(EW <= EL, "ELL width exceeds the lanes of a row group");
   const int bid = blockIdx.x;
   int b, rb;
   if (xcd_map) {
@@ -45,108 +54,179 @@ __global__ __launch_bounds__(256) void agg_kernel(const int32_t* __restrict__ ro
   const int sub = lane / LPR;
   const int l = lane % LPR;
   const int gbase = sub * LPR;  // first lane of this row's group
-  const int row = rb * RPB + wave * RPW + sub;
-  const bool ractive = row < n;
   const int c0 = l * 4;
   const bool cactive = c0 < F;
+  const int cc = cactive ? c0 : 0;  // inactive channel lanes re-read channel 0 (never stored)
   const float* __restrict__ Hb = H + (int64_t)b * bsh;
+  float* __restrict__ Yb = Y + (int64_t)b * bsy;
 
-  int start = 0, end = 0;
-  if (ractive) {
-    start = rowptr[row];
-    end = rowptr[row + 1];
+  float bz0 = 0.f, bz1 = 0.f, bz2 = 0.f, bz3 = 0.f;
+  if (bias && cactive) {
+    bz0 = bias[c0];
+    if (VS || c0 + 1 < F) bz1 = bias[c0 + 1];
+    if (VS || c0 + 2 < F) bz2 = bias[c0 + 2];
+    if (VS || c0 + 3 < F) bz3 = bias[c0 + 3];
   }
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 
   auto ld4 = [&](int j, float& x0, float& x1, float& x2, float& x3) {
-    const float* p = Hb + (int64_t)j * ldh + c0;
+    const float* p = Hb + (int64_t)j * ldh + cc;
     if (VL) {
       const float4 v = *reinterpret_cast<const float4*>(p);
       x0 = v.x; x1 = v.y; x2 = v.z; x3 = v.w;
     } else {
       x0 = p[0];
-      x1 = (c0 + 1 < F) ? p[1] : 0.f;
-      x2 = (c0 + 2 < F) ? p[2] : 0.f;
-      x3 = (c0 + 3 < F) ? p[3] : 0.f;
+      x1 = (cc + 1 < F) ? p[1] : 0.f;
+      x2 = (cc + 2 < F) ? p[2] : 0.f;
+      x3 = (cc + 3 < F) ? p[3] : 0.f;
     }
   };
 
-  for (int base = start; base < end; base += LPR) {
-    const int mine = base + l;
-    int cj = 0;
-    float wj = 0.f;
-    if (mine < end) {
-      cj = col[mine];
-      wj = w[mine];
-    }
-    const int cnt = min(LPR, end - base);
-    for (int k = 0; k < cnt; k += 4) {
-      // indices/weights of up to 4 neighbours, broadcast from the lanes of this row's group
-      const int j0 = __shfl(cj, gbase + k, 64);
-      const int j1 = __shfl(cj, gbase + ((k + 1) & (LPR - 1)), 64);
-      const int j2 = __shfl(cj, gbase + ((k + 2) & (LPR - 1)), 64);
-      const int j3 = __shfl(cj, gbase + ((k + 3) & (LPR - 1)), 64);
-      const float w0 = __shfl(wj, gbase + k, 64);
-      const float w1 = __shfl(wj, gbase + ((k + 1) & (LPR - 1)), 64);
-      const float w2 = __shfl(wj, gbase + ((k + 2) & (LPR - 1)), 64);
-      const float w3 = __shfl(wj, gbase + ((k + 3) & (LPR - 1)), 64);
-      float p0 = 0, p1 = 0, p2 = 0, p3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-      float r0 = 0, r1 = 0, r2 = 0, r3 = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-      if (cactive) {
-        ld4(j0, p0, p1, p2, p3);
-        if (k + 1 < cnt) ld4(j1, q0, q1, q2, q3);
-        if (k + 2 < cnt) ld4(j2, r0, r1, r2, r3);
-        if (k + 3 < cnt) ld4(j3, s0, s1, s2, s3);
-      }
-      a0 += w0 * p0; a1 += w0 * p1; a2 += w0 * p2; a3 += w0 * p3;
-      if (k + 1 < cnt) { a0 += w1 * q0; a1 += w1 * q1; a2 += w1 * q2; a3 += w1 * q3; }
-      if (k + 2 < cnt) { a0 += w2 * r0; a1 += w2 * r1; a2 += w2 * r2; a3 += w2 * r3; }
-      if (k + 3 < cnt) { a0 += w3 * s0; a1 += w3 * s1; a2 += w3 * s2; a3 += w3 * s3; }
-    }
-  }
+  // metadata of one batch: loaded unconditionally (rows past the end are clamped, masked at store)
+  const int row_first = (rb * 4 + wave) * (RPW * ITER) + sub;
+  auto meta = [&](int row, int& start, int& end, int& cj, float& wj) {
+    const int rc = row < n ? row : n - 1;
+    start = rowptr[rc];
+    end = rowptr[rc + 1];
+    cj = ecol[(int64_t)rc * gcl::kEll + (l & (EL - 1))];
+    wj = ew[(int64_t)rc * gcl::kEll + (l & (EL - 1))];
+  };
+  int start, end, cj;
+  float wj;
+  meta(row_first, start, end, cj, wj);
 
-  if (!ractive || !cactive) return;
-  if (bias) {
-    if (VS || c0 + 3 < F) {
-      a0 += bias[c0]; a1 += bias[c0 + 1]; a2 += bias[c0 + 2]; a3 += bias[c0 + 3];
-    } else {
-      a0 += bias[c0];
-      if (c0 + 1 < F) a1 += bias[c0 + 1];
-      if (c0 + 2 < F) a2 += bias[c0 + 2];
+#pragma unroll 1
+  for (int it = 0; it < ITER; ++it) {
+    const int row = row_first + it * RPW;
+    int nstart = 0, nend = 0, ncj = 0;
+    float nwj = 0.f;
+    if (it + 1 < ITER) meta(row + RPW, nstart, nend, ncj, nwj);  // next batch, in flight during this one
+
+    const int deg = end - start;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    {
+      int jj[EW];
+      float ww[EW], v0[EW], v1[EW], v2[EW], v3[EW];
+#pragma unroll
+      for (int k = 0; k < EW; ++k) {
+        jj[k] = __shfl(cj, gbase + k, 64);
+        ww[k] = __shfl(wj, gbase + k, 64);
+      }
+#pragma unroll
+      for (int k = 0; k < EW; ++k) ld4(jj[k], v0[k], v1[k], v2[k], v3[k]);  // EW rows in flight
+#pragma unroll
+      for (int k = 0; k < EW; ++k) {
+        const bool in = k < deg;
+        a0 += in ? ww[k] * v0[k] : 0.f;
+        a1 += in ? ww[k] * v1[k] : 0.f;
+        a2 += in ? ww[k] * v2[k] : 0.f;
+        a3 += in ? ww[k] * v3[k] : 0.f;
+      }
     }
-  }
-  float* __restrict__ yp = Y + (int64_t)b * bsy + (int64_t)row * ldy + c0;
-  if (VS) {
-    *reinterpret_cast<float4*>(yp) = make_float4(a0, a1, a2, a3);
-  } else {
-    yp[0] = a0;
-    if (c0 + 1 < F) yp[1] = a1;
-    if (c0 + 2 < F) yp[2] = a2;
-    if (c0 + 3 < F) yp[3] = a3;
+    if (__any(deg > EW)) {  // wave-uniform: some row of this wave has more edges than the prefix
+      for (int base = start + EW; base < end; base += LPR) {
+        const int mine = base + l;
+        int oj = 0;
+        float ow = 0.f;
+        if (mine < end) {
+          oj = col[mine];
+          ow = w[mine];
+        }
+        const int cnt = min(LPR, end - base);
+        for (int k = 0; k < cnt; k += 4) {
+          const int j0 = __shfl(oj, gbase + k, 64);
+          const int j1 = __shfl(oj, gbase + ((k + 1) & (LPR - 1)), 64);
+          const int j2 = __shfl(oj, gbase + ((k + 2) & (LPR - 1)), 64);
+          const int j3 = __shfl(oj, gbase + ((k + 3) & (LPR - 1)), 64);
+          const float w0 = __shfl(ow, gbase + k, 64);
+          const float w1 = __shfl(ow, gbase + ((k + 1) & (LPR - 1)), 64);
+          const float w2 = __shfl(ow, gbase + ((k + 2) & (LPR - 1)), 64);
+          const float w3 = __shfl(ow, gbase + ((k + 3) & (LPR - 1)), 64);
+          float p0 = 0, p1 = 0, p2 = 0, p3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+          float r0 = 0, r1 = 0, r2 = 0, r3 = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+          ld4(j0, p0, p1, p2, p3);
+          if (k + 1 < cnt) ld4(j1, q0, q1, q2, q3);
+          if (k + 2 < cnt) ld4(j2, r0, r1, r2, r3);
+          if (k + 3 < cnt) ld4(j3, s0, s1, s2, s3);
+          a0 += w0 * p0; a1 += w0 * p1; a2 += w0 * p2; a3 += w0 * p3;
+          if (k + 1 < cnt) { a0 += w1 * q0; a1 += w1 * q1; a2 += w1 * q2; a3 += w1 * q3; }
+          if (k + 2 < cnt) { a0 += w2 * r0; a1 += w2 * r1; a2 += w2 * r2; a3 += w2 * r3; }
+          if (k + 3 < cnt) { a0 += w3 * s0; a1 += w3 * s1; a2 += w3 * s2; a3 += w3 * s3; }
+        }
+      }
+    }
+    if (row < n && cactive) {
+      a0 += bz0; a1 += bz1; a2 += bz2; a3 += bz3;
+      float* __restrict__ yp = Yb + (int64_t)row * ldy + c0;
+      if (VS) {
+        *reinterpret_cast<float4*>(yp) = make_float4(a0, a1, a2, a3);
+      } else {
+        yp[0] = a0;
+        if (c0 + 1 < F) yp[1] = a1;
+        if (c0 + 2 < F) yp[2] = a2;
+        if (c0 + 3 < F) yp[3] = a3;
+      }
+    }
+    start = nstart; end = nend; cj = ncj; wj = nwj;
   }
 }
 
+int agg_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+struct AggArgs {
+  const int32_t *rowptr, *col, *ecol;
+  const float *w, *ew;
+  int ell_width;
+};
+
 template <int LPR>
-int launch_agg(const int32_t* rowptr, const int32_t* col, const float* w, const float* h, int64_t ldh, int64_t bsh,
-               const float* bias, float* y, int64_t ldy, int64_t bsy, int32_t n, int32_t B, int32_t F,
-               hipStream_t st) {
-  constexpr int RPB = (64 / LPR) * 4;
-  const int32_t nRB = (int32_t)gcl::cdiv(n, RPB);
-  const int xcd_map = B >= gcl::kNumXCD ? 1 : 0;
-  const int64_t nb = xcd_map ? (int64_t)gcl::kNumXCD * gcl::cdiv(B, gcl::kNumXCD) * nRB : (int64_t)B * nRB;
-  GCL_CHECK_ARG(nb < (int64_t)INT32_MAX, "aggregate: grid too large");
+int launch_agg(const AggArgs& ga, const float* h, int64_t ldh, int64_t bsh, const float* bias, float* y, int64_t ldy,
+               int64_t bsy, int32_t n, int32_t B, int32_t F, hipStream_t st) {
+  constexpr int RPW = 64 / LPR;
+  constexpr int EL = LPR < gcl::kEll ? LPR : gcl::kEll;
   // vector loads need 16-B aligned rows and a padded tail (ldh >= roundup(F,4))
   const bool vl = (ldh % 4 == 0) && (bsh % 4 == 0) && gcl::aligned16(h) && ldh >= ((F + 3) / 4) * 4;
   const bool vs = (ldy % 4 == 0) && (bsy % 4 == 0) && gcl::aligned16(y) && (F % 4 == 0);
+  static const int iter_env = agg_env("GCL_AGG_ITER", 0);  // tuning overrides (0 = per-graph default)
+  static const int ew_env = agg_env("GCL_AGG_EW", 0);
+  int ewidth = ew_env > 0 ? ew_env : ga.ell_width;
+  if (ewidth > EL) ewidth = EL;
+  ewidth = ewidth >= 8 ? 8 : ewidth >= 4 ? 4 : ewidth >= 2 ? 2 : 1;
+  // measured on MI355X (profiles/r01_c_*): dense prefixes (mesh) run best with one batch per wave,
+  // near-diagonal bipartite graphs with two (next batch's metadata prefetched)
+  const int iter = (iter_env == 1 || iter_env == 2 || iter_env == 4 || iter_env == 8) ? iter_env
+                                                                                       : (ewidth >= 4 ? 1 : 2);
+  const int32_t nRB = (int32_t)gcl::cdiv(n, RPW * 4 * iter);
+  const int xcd_map = B >= gcl::kNumXCD ? 1 : 0;
+  const int64_t nb = xcd_map ? (int64_t)gcl::kNumXCD * gcl::cdiv(B, gcl::kNumXCD) * nRB : (int64_t)B * nRB;
+  GCL_CHECK_ARG(nb < (int64_t)INT32_MAX, "aggregate: grid too large");
   dim3 grid((unsigned)nb), block(256);
-#define GCL_AGG(VL_, VS_)                                                                                     \
-  hipLaunchKernelGGL((agg_kernel<LPR, VL_, VS_>), grid, block, 0, st, rowptr, col, w, h, ldh, bsh, bias, y, ldy, \
-                     bsy, n, B, F, nRB, xcd_map)
-  if (vl && vs) GCL_AGG(true, true);
-  else if (vl) GCL_AGG(true, false);
-  else if (vs) GCL_AGG(false, true);
-  else GCL_AGG(false, false);
-#undef GCL_AGG
+#define GCL_AGG4(VL_, VS_, EW_, IT_)                                                                             \
+  hipLaunchKernelGGL((agg_kernel<LPR, VL_, VS_, EW_, IT_>), grid, block, 0, st, ga.rowptr, ga.col, ga.w, ga.ecol, \
+                     ga.ew, h, ldh, bsh, bias, y, ldy, bsy, n, B, F, nRB, xcd_map)
+#define GCL_AGG3(VL_, VS_, EW_)              \
+  do {                                       \
+    if (iter == 8) GCL_AGG4(VL_, VS_, EW_, 8); \
+    else if (iter == 4) GCL_AGG4(VL_, VS_, EW_, 4); \
+    else if (iter == 2) GCL_AGG4(VL_, VS_, EW_, 2); \
+    else GCL_AGG4(VL_, VS_, EW_, 1);         \
+  } while (0)
+#define GCL_AGG2(VL_, VS_)                                        \
+  do {                                                            \
+    if constexpr (EL >= 8) { if (ewidth == 8) { GCL_AGG3(VL_, VS_, 8); break; } } \
+    if (ewidth >= 4) GCL_AGG3(VL_, VS_, 4);                       \
+    else if (ewidth == 2) GCL_AGG3(VL_, VS_, 2);                  \
+    else GCL_AGG3(VL_, VS_, 1);                                   \
+  } while (0)
+  if (vl && vs) GCL_AGG2(true, true);
+  else if (vl) GCL_AGG2(true, false);
+  else if (vs) GCL_AGG2(false, true);
+  else GCL_AGG2(false, false);
+#undef GCL_AGG2
+#undef GCL_AGG3
+#undef GCL_AGG4
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
@@ -161,14 +241,18 @@ extern "C" int gcl_aggregate(const gcl_graph_t* g, int32_t transpose, const floa
   GCL_CHECK_ARG(ldh >= F && ldy >= F, "aggregate: leading dimension smaller than F");
   GCL_CHECK_ARG(g->kind != GCL_GRAPH_GAT, "aggregate: GAT graphs carry no edge weights; use gcl_gat_fwd");
   GCL_CHECK_ARG(h != y, "aggregate: in-place aggregation is not supported");
-  const int32_t* rp = transpose ? g->trowptr : g->rowptr;
-  const int32_t* cl = transpose ? g->tcol : g->col;
-  const float* ww = transpose ? g->tw : g->w;
+  AggArgs ga;
+  ga.rowptr = transpose ? g->trowptr : g->rowptr;
+  ga.col = transpose ? g->tcol : g->col;
+  ga.w = transpose ? g->tw : g->w;
+  ga.ecol = transpose ? g->tecol : g->ecol;
+  ga.ew = transpose ? g->tew : g->ew;
+  ga.ell_width = transpose ? g->tell_width : g->ell_width;
   hipStream_t st = (hipStream_t)stream;
   const int lanes = (F + 3) / 4;
-  if (lanes <= 4) return launch_agg<4>(rp, cl, ww, h, ldh, bsh, bias, y, ldy, bsy, g->n, B, F, st);
-  if (lanes <= 8) return launch_agg<8>(rp, cl, ww, h, ldh, bsh, bias, y, ldy, bsy, g->n, B, F, st);
-  if (lanes <= 16) return launch_agg<16>(rp, cl, ww, h, ldh, bsh, bias, y, ldy, bsy, g->n, B, F, st);
-  if (lanes <= 32) return launch_agg<32>(rp, cl, ww, h, ldh, bsh, bias, y, ldy, bsy, g->n, B, F, st);
-  return launch_agg<64>(rp, cl, ww, h, ldh, bsh, bias, y, ldy, bsy, g->n, B, F, st);
+  if (lanes <= 4) return launch_agg<4>(ga, h, ldh, bsh, bias, y, ldy, bsy, g->n, B, F, st);
+  if (lanes <= 8) return launch_agg<8>(ga, h, ldh, bsh, bias, y, ldy, bsy, g->n, B, F, st);
+  if (lanes <= 16) return launch_agg<16>(ga, h, ldh, bsh, bias, y, ldy, bsy, g->n, B, F, st);
+  if (lanes <= 32) return launch_agg<32>(ga, h, ldh, bsh, bias, y, ldy, bsy, g->n, B, F, st);
+  return launch_agg<64>(ga, h, ldh, bsh, bias, y, ldy, bsy, g->n, B, F, st);
 }

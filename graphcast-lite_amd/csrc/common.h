@@ -43,6 +43,7 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 constexpr int kWave = 64;     // CDNA wavefront
 constexpr int kNumXCD = 8;    // MI355X: 8 XCDs, blocks are dealt round-robin over them
 constexpr int kNumCU = 256;
+constexpr int kEll = 8;      // stride of the ELL prefix arrays
 
 __device__ __forceinline__ float prelu_f(float x, float a) { return x > 0.f ? x : a * x; }
 
@@ -62,6 +63,10 @@ struct gcl_graph {
   int32_t *rowptr = nullptr, *col = nullptr, *eperm = nullptr;
   int32_t *trowptr = nullptr, *tcol = nullptr, *tslot = nullptr;
   float *w = nullptr, *tw = nullptr;
+  // fixed-stride prefix of every row (first kEll edges in CSR order; padding: col = row, w = 0)
+  int32_t *ecol = nullptr, *tecol = nullptr;
+  float *ew = nullptr, *tew = nullptr;
+  int32_t ell_width = 8, tell_width = 8;  // how many prefix entries the kernels read unconditionally
   // host copy of the PyG-order edge list with loops (for export / prune)
   int64_t* h_edges = nullptr;  // [2, e]
 };

@@ -131,7 +131,8 @@ static int upload(T** dst, const T* src, size_t count) {
 
 extern "C" void gcl_graph_destroy(gcl_graph_t* g) {
   if (!g) return;
-  void* ptrs[] = {g->rowptr, g->col, g->eperm, g->trowptr, g->tcol, g->tslot, g->w, g->tw};
+  void* ptrs[] = {g->rowptr, g->col, g->eperm, g->trowptr, g->tcol, g->tslot, g->w, g->tw,
+                  g->ecol, g->tecol, g->ew, g->tew};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   free(g->h_edges);
@@ -178,6 +179,41 @@ extern "C" int gcl_graph_create(const int64_t* ei, int64_t E, int32_t n, int32_t
   if (!rc) rc = upload(&g->tcol, tcol.data(), Ep);
   if (!rc) rc = upload(&g->tw, tw.data(), Ep);
   if (!rc) rc = upload(&g->tslot, tslot.data(), Ep);
+  // ELL prefixes (forward and transpose) + the width that covers most rows
+  auto build_ell = [&](const std::vector<int32_t>& rp, const std::vector<int32_t>& cl, const std::vector<float>& ww,
+                       std::vector<int32_t>& ec, std::vector<float>& ewv) -> int {
+    ec.assign((size_t)n * gcl::kEll, 0);
+    ewv.assign((size_t)n * gcl::kEll, 0.f);
+    int64_t hist[gcl::kEll + 2] = {0};
+    for (int32_t i = 0; i < n; ++i) {
+      const int32_t d = rp[i + 1] - rp[i];
+      hist[d > gcl::kEll ? gcl::kEll + 1 : d]++;
+      for (int k = 0; k < gcl::kEll; ++k) {
+        const bool in = k < d;
+        ec[(size_t)i * gcl::kEll + k] = in ? cl[rp[i] + k] : i;
+        ewv[(size_t)i * gcl::kEll + k] = in ? ww[rp[i] + k] : 0.f;
+      }
+    }
+    // smallest power-of-two width that holds >= 80 % of the rows completely (rest: CSR overflow loop)
+    int64_t cum = 0;
+    int width = gcl::kEll;
+    for (int d = 0; d <= gcl::kEll; ++d) {
+      cum += hist[d];
+      if (cum * 10 >= (int64_t)n * 8) {
+        width = d <= 1 ? 1 : d <= 2 ? 2 : d <= 4 ? 4 : 8;
+        break;
+      }
+    }
+    return width;
+  };
+  std::vector<int32_t> ec, tec;
+  std::vector<float> ewv, tewv;
+  g->ell_width = build_ell(rowptr, col, w, ec, ewv);
+  g->tell_width = build_ell(trowptr, tcol, tw, tec, tewv);
+  if (!rc) rc = upload(&g->ecol, ec.data(), ec.size());
+  if (!rc) rc = upload(&g->ew, ewv.data(), ewv.size());
+  if (!rc) rc = upload(&g->tecol, tec.data(), tec.size());
+  if (!rc) rc = upload(&g->tew, tewv.data(), tewv.size());
   if (rc) {
     gcl_graph_destroy(g);
     return rc;

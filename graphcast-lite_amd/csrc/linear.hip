@@ -457,6 +457,233 @@ __global__ __launch_bounds__(256, (DwCfg<NO, NC>::min_waves)) void dw_mfma_kerne
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused backward of  y = act(x) W^T (+ b):  one pass over dY and the pre-activation input P.
+//   dX[r,c]  = (sum_o dY[r,o] W[o,c]) * PReLU'(P[r,c])          -> global (raw buffer stores)
+//   dW[o,c] += sum_r dY[r,o] act(P[r,c])                         -> per-block partial tiles
+//   db[o]   += sum_r dY[r,o],  cs[c] += sum_r dX[r,c],  dslope += sum dX_preact * min(0,P)
+// Traffic per call: read dY + read P + write dX (600 MB at 786k x 64) instead of the 1600 MB the
+// separate dx / dW / colsum launches move, because P doubles as Z (PReLU') and as X (dW), and dY
+// is read once.  One 4-wave block per CU (LDS ~84 KB at 64x64), one wave per SIMD, explicit
+// register prefetch of the next tile during the ~8k MFMA cycles of the current one.
+//   LDS: Wt[FiP][KPo] (W transposed, for dX), dYl[128][KPo] (row-major: A of dX as 8-B fragments,
+//   A' of dW as channel-contiguous 4-B fragments), Pl[128][FiP] (pre-activation; PReLU is applied
+//   when the B' fragment is formed, PReLU' in the dX epilogue).
+// Constraints (else the caller falls back to the separate kernels): Fout <= 64, Fin <= 96,
+// Fout % 4 == Fin % 4 == 0, 16-B aligned rows.
+// ---------------------------------------------------------------------------------------------
+template <int NO, int NC>
+__global__ __launch_bounds__(256, 1) void linear_bwd_fused_kernel(
+    const float* __restrict__ dY, int64_t lddy, const float* __restrict__ W, const float* __restrict__ P,
+    int64_t ldp, const float* __restrict__ in_slope, float* __restrict__ dX, int64_t lddx, int64_t rows, int32_t Fin,
+    int32_t Fout, float* __restrict__ part_dw, float* __restrict__ part_db, float* __restrict__ part_cs,
+    double* __restrict__ part_slope) {
+  constexpr int FoP = NO * 32, FiP = NC * 32;
+  constexpr int KPo = FoP + 2;             // even stride, KPo/2 odd
+  constexpr int TM = 128;
+  constexpr int NT = NO * NC;              // dW tiles
+  constexpr int TPW = (NT + 3) / 4;        // dW tiles per wave
+  constexpr int CY = FoP / 4;              // float4 columns of a dY row (8 or 16)
+  constexpr int CP = NC == 3 ? 32 : FiP / 4;  // float4 column slots of a P row (power of two)
+  constexpr int RY = 64 / CY, RP = 64 / CP;   // rows per wave-instruction
+  constexpr int NY = 32 / RY, NP = 32 / RP;   // wave-instructions per 32-row slice
+  extern __shared__ __align__(16) float smem[];
+  float* Wt = smem;                         // [FiP][KPo]
+  float* dYl = Wt + FiP * KPo;              // [TM][KPo]
+  float* Pl = dYl + TM * KPo;               // [TM][FiP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+
+  for (int idx = tid; idx < FiP * FoP; idx += 256) {  // Wt[c][o] = W[o][c], zero padded
+    const int c = idx / FoP, o = idx - c * FoP;
+    Wt[c * KPo + o] = (c < Fin && o < Fout) ? W[(int64_t)o * Fin + c] : 0.f;
+  }
+  const bool act = in_slope != nullptr;
+  const float slope = act ? *in_slope : 1.f;
+  const int64_t ntiles = (rows + TM - 1) / TM;
+
+  f32x16 dw[TPW];
+#pragma unroll
+  for (int q = 0; q < TPW; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dw[q][r] = 0.f;
+  float dbacc[TPW], cs[NC];
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) dbacc[q] = 0.f;
+#pragma unroll
+  for (int s2 = 0; s2 < NC; ++s2) cs[s2] = 0.f;
+  double slope_acc = 0.0;
+
+  const int ysub = lane / CY, ycol = lane % CY, psub = lane / CP, pcol = lane % CP;
+  float4 pre[NY + NP];
+  const float4* zero = gcl_zero4;
+  auto issue = [&](int64_t tile) {
+    const int64_t r0 = tile * TM + wave * 32;
+#pragma unroll
+    for (int it = 0; it < NY; ++it) {
+      const int64_t row = r0 + it * RY + ysub;
+      const bool ok = (ycol * 4 < Fout) && (row < rows);
+      pre[it] = *(ok ? reinterpret_cast<const float4*>(dY + row * lddy + ycol * 4) : zero);
+    }
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const int64_t row = r0 + it * RP + psub;
+      const bool ok = (pcol * 4 < Fin) && (row < rows);
+      pre[NY + it] = *(ok ? reinterpret_cast<const float4*>(P + row * ldp + pcol * 4) : zero);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < NY; ++it) {
+      const int r = wave * 32 + it * RY + ysub;
+      float2* d = reinterpret_cast<float2*>(dYl + r * KPo + ycol * 4);
+      const float4 v = pre[it];
+      d[0] = make_float2(v.x, v.y);
+      d[1] = make_float2(v.z, v.w);
+    }
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const int r = wave * 32 + it * RP + psub;
+      const float4 v = pre[NY + it];
+      if (pcol * 4 < FiP) *reinterpret_cast<float4*>(Pl + r * FiP + pcol * 4) = v;
+    }
+  };
+
+  issue(blockIdx.x);
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    issue(t + gridDim.x);
+
+    const int64_t r0 = t * TM;
+    const int64_t nr = (rows - r0) < TM ? (rows - r0) : TM;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(dX + r0 * lddx, win_bytes(nr, lddx, Fin));
+
+    // ---- dX slice of this wave: [32 x Fin] = dYl[32 rows] (K = Fout) x Wt ----
+    f32x16 acc[NC];
+#pragma unroll
+    for (int s2 = 0; s2 < NC; ++s2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s2][r] = 0.f;
+    {
+      const float* ap = dYl + (wave * 32 + li) * KPo + 2 * lk;
+      const float* bp = Wt + li * KPo + 2 * lk;
+      constexpr int nq = FoP / 4;
+      float2 a_c = *reinterpret_cast<const float2*>(ap);
+      float2 b_c[NC];
+#pragma unroll
+      for (int s2 = 0; s2 < NC; ++s2) b_c[s2] = *reinterpret_cast<const float2*>(bp + s2 * 32 * KPo);
+#pragma unroll 2
+      for (int q = 0; q < nq; ++q) {
+        const int qn = (q + 1 < nq) ? q + 1 : q;
+        const float2 a_n = *reinterpret_cast<const float2*>(ap + qn * 4);
+        float2 b_n[NC];
+#pragma unroll
+        for (int s2 = 0; s2 < NC; ++s2) b_n[s2] = *reinterpret_cast<const float2*>(bp + s2 * 32 * KPo + qn * 4);
+#pragma unroll
+        for (int s2 = 0; s2 < NC; ++s2)
+          acc[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c.x, b_c[s2].x, acc[s2], 0, 0, 0);
+#pragma unroll
+        for (int s2 = 0; s2 < NC; ++s2)
+          acc[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c.y, b_c[s2].y, acc[s2], 0, 0, 0);
+        a_c = a_n;
+#pragma unroll
+        for (int s2 = 0; s2 < NC; ++s2) b_c[s2] = b_n[s2];
+      }
+    }
+    // epilogue: PReLU' from the LDS copy of P, slope / column-sum accumulation, unconditional stores
+#pragma unroll
+    for (int s2 = 0; s2 < NC; ++s2) {
+      const int j = s2 * 32 + li;
+      const bool jok = j < Fin;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = wave * 32 + d_row(r, lane);
+        float v = acc[s2][r];
+        if (act) {
+          const float z = Pl[rr * FiP + j];
+          if (z <= 0.f) {
+            slope_acc += (double)(v * z);
+            v *= slope;
+          }
+        }
+        cs[s2] += v;
+        buf_st1(rx, jok ? (unsigned)((rr * lddx + j) * 4) : kOOB, v);
+      }
+    }
+
+    // ---- dW tiles of this wave over all 128 rows of the tile ----
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+      const int tix = wave + 4 * q;
+      if (tix < NT) {  // wave-uniform
+        const int so = tix % NO, sc = tix / NO;
+        const float* yp = dYl + lk * KPo + so * 32 + li;
+        const float* xp = Pl + lk * FiP + sc * 32 + li;
+        constexpr int DP = 4;  // LDS fragments are read 4 row pairs ahead of their MFMAs
+        float av[DP], bv[DP];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+          av[d] = yp[(2 * d) * KPo];
+          bv[d] = xp[(2 * d) * FiP];
+        }
+        for (int k = 0; k < TM; k += 2 * DP) {
+          float an[DP], bn[DP];
+#pragma unroll
+          for (int d = 0; d < DP; ++d) {
+            const int kn = (k + 2 * DP + 2 * d < TM) ? k + 2 * DP + 2 * d : 2 * d;
+            an[d] = yp[kn * KPo];
+            bn[d] = xp[kn * FiP];
+          }
+#pragma unroll
+          for (int d = 0; d < DP; ++d) {
+            const float bx = act ? gcl::prelu_f(bv[d], slope) : bv[d];
+            if (sc == 0) dbacc[q] += av[d];
+            dw[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[d], bx, dw[q], 0, 0, 0);
+          }
+#pragma unroll
+          for (int d = 0; d < DP; ++d) {
+            av[d] = an[d];
+            bv[d] = bn[d];
+          }
+        }
+      }
+    }
+  }
+
+  // ---- per-block partials ----
+  float* out = part_dw + (size_t)blockIdx.x * FoP * FiP;
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const int tix = wave + 4 * q;
+    if (tix < NT) {
+      const int so = tix % NO, sc = tix / NO;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[(size_t)(so * 32 + d_row(r, lane)) * FiP + sc * 32 + li] = dw[q][r];
+      if (part_db && sc == 0) {
+        const float d = dbacc[q] + __shfl_xor(dbacc[q], 32, 64);
+        if (lane < 32) part_db[(size_t)blockIdx.x * FoP + so * 32 + lane] = d;
+      }
+    }
+  }
+  __syncthreads();  // LDS is free: reuse it for the cross-wave column sums and the slope partial
+  float* red = smem;  // [4][FiP]
+#pragma unroll
+  for (int s2 = 0; s2 < NC; ++s2) {
+    const float v = cs[s2] + __shfl_xor(cs[s2], 32, 64);
+    if (lane < 32) red[wave * FiP + s2 * 32 + lane] = v;
+  }
+  for (int off = 32; off > 0; off >>= 1) slope_acc += __shfl_down(slope_acc, off, 64);
+  double* dred = reinterpret_cast<double*>(smem + 4 * FiP);
+  if (lane == 0) dred[wave] = slope_acc;
+  __syncthreads();
+  if (part_cs)
+    for (int c = tid; c < FiP; c += 256)
+      part_cs[(size_t)blockIdx.x * FiP + c] = (red[c] + red[FiP + c]) + (red[2 * FiP + c] + red[3 * FiP + c]);
+  if (part_slope && tid == 0) part_slope[blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
+}
+
 // out[i*ldo + j] (+)= sum_p part[p*pstride + i*pld + j]   for i < R, j < C.
 // 64 outputs per block, 4 thread groups split the partials, combined through LDS (fixed order).
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int32_t nparts,
@@ -603,6 +830,9 @@ int launch_linear(const float* X, int64_t ldx, const float* in_slope, const floa
 
 }  // namespace
 
+extern "C" size_t gcl_colsum_ws_bytes(int64_t, int32_t);
+extern "C" int gcl_colsum(const float*, int64_t, int64_t, int32_t, float*, int32_t, void*, size_t, gcl_stream_t);
+
 extern "C" int gcl_linear_fwd(const float* x, int64_t ldx, const float* in_slope, const float* W, const float* bias,
                               float* y, int64_t ldy, int64_t rows, int32_t Fin, int32_t Fout, gcl_stream_t stream) {
   GCL_CHECK_ARG(x && W && y, "linear_fwd: null argument");
@@ -708,6 +938,87 @@ extern "C" int gcl_linear_bwd_dw(const float* dy, int64_t lddy, const float* x, 
   if (db) {
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)gcl::cdiv(Fout, 64)), dim3(256), 0, st, dbpart, (int)nblk,
                        (int64_t)FoutP, FoutP, db, Fout, 1, Fout, accumulate);
+    GCL_CHECK_LAUNCH();
+  }
+  return GCL_OK;
+}
+
+// Fused path geometry / workspace (see linear_bwd_fused_kernel)
+static bool fused_ok(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* dx, int64_t lddx,
+                     int32_t Fin, int32_t Fout) {
+  static int off = -1;
+  if (off < 0) {
+    const char* e = getenv("GCL_NO_FUSED_BWD");
+    off = (e && atoi(e) != 0) ? 1 : 0;
+  }
+  if (off || use_valu()) return false;
+  return Fout <= 64 && Fin <= 96 && (Fout % 4 == 0) && (Fin % 4 == 0) && (lddy % 4 == 0) && (ldx % 4 == 0) &&
+         (lddx >= Fin) && gcl::aligned16(dy) && gcl::aligned16(x) && dx != nullptr;
+}
+
+extern "C" size_t gcl_linear_bwd_all_ws_bytes(int64_t rows, int32_t Fin, int32_t Fout) {
+  const size_t FiP = (size_t)((Fin + 31) / 32) * 32, FoP = (size_t)((Fout + 31) / 32) * 32;
+  const size_t fused = (size_t)gcl::kNumCU * (FoP * FiP + FoP + FiP) * sizeof(float) + (size_t)gcl::kNumCU * 8 + 64;
+  size_t sep = gcl_linear_bwd_ws_bytes(rows, Fin, Fout);
+  const size_t cs = gcl_colsum_ws_bytes(rows, Fin);
+  if (cs > sep) sep = cs;
+  return fused > sep ? fused : sep;
+}
+
+extern "C" int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W, const float* x, int64_t ldx,
+                                  const float* in_slope, float* d_in_slope, float* dx, int64_t lddx, float* dW,
+                                  float* db, float* colsum_dx, int64_t rows, int32_t Fin, int32_t Fout,
+                                  int32_t accumulate, void* ws, size_t ws_bytes, gcl_stream_t stream) {
+  GCL_CHECK_ARG(dy && W && x && dx && dW, "linear_bwd_all: null argument");
+  GCL_CHECK_ARG(ws && ws_bytes >= gcl_linear_bwd_all_ws_bytes(rows, Fin, Fout), "linear_bwd_all: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (!fused_ok(dy, lddy, x, ldx, dx, lddx, Fin, Fout) || rows == 0) {
+    int rc = gcl_linear_bwd_dw(dy, lddy, x, ldx, in_slope, dW, db, rows, Fin, Fout, accumulate, ws, ws_bytes, stream);
+    if (rc) return rc;
+    rc = gcl_linear_bwd_dx(dy, lddy, W, in_slope ? x : nullptr, ldx, in_slope, d_in_slope, dx, lddx, rows, Fin, Fout,
+                           ws, ws_bytes, stream);
+    if (rc) return rc;
+    if (colsum_dx) rc = gcl_colsum(dx, lddx, rows, Fin, colsum_dx, accumulate, ws, ws_bytes, stream);
+    return rc;
+  }
+  const int NO = (Fout + 31) / 32, NC = (Fin + 31) / 32;
+  const int FoP = NO * 32, FiP = NC * 32;
+  const int64_t ntiles = gcl::cdiv(rows, 128);
+  const int nblk = (int)(ntiles < gcl::kNumCU ? ntiles : gcl::kNumCU);
+  float* part_dw = (float*)ws;
+  float* part_db = part_dw + (size_t)gcl::kNumCU * FoP * FiP;
+  float* part_cs = part_db + (size_t)gcl::kNumCU * FoP;
+  double* part_sl = (double*)(((uintptr_t)(part_cs + (size_t)gcl::kNumCU * FiP) + 15) & ~(uintptr_t)15);
+  const size_t lds = ((size_t)FiP * (FoP + 2) + 128 * (size_t)(FoP + 2) + 128 * (size_t)FiP) * sizeof(float);
+  const bool want_slope = in_slope && d_in_slope;
+#define GCL_FB(NO_, NC_)                                                                                          \
+  do {                                                                                                            \
+    auto kern = linear_bwd_fused_kernel<NO_, NC_>;                                                                \
+    GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, dy, lddy, W, x, ldx, in_slope, dx, lddx, rows, Fin,  \
+                       Fout, part_dw, db ? part_db : nullptr, colsum_dx ? part_cs : nullptr,                      \
+                       want_slope ? part_sl : nullptr);                                                           \
+  } while (0)
+  if (NO == 1 && NC == 1) GCL_FB(1, 1);
+  else if (NO == 1 && NC == 2) GCL_FB(1, 2);
+  else if (NO == 1 && NC == 3) GCL_FB(1, 3);
+  else if (NO == 2 && NC == 1) GCL_FB(2, 1);
+  else if (NO == 2 && NC == 2) GCL_FB(2, 2);
+  else GCL_FB(2, 3);
+#undef GCL_FB
+  GCL_CHECK_LAUNCH();
+  int rc = gcl::launch_reduce_parts(part_dw, nblk, (int64_t)FoP * FiP, FiP, dW, Fin, Fout, Fin, accumulate, st);
+  if (rc) return rc;
+  if (db) {
+    rc = gcl::launch_reduce_parts(part_db, nblk, FoP, FoP, db, Fout, 1, Fout, accumulate, st);
+    if (rc) return rc;
+  }
+  if (colsum_dx) {
+    rc = gcl::launch_reduce_parts(part_cs, nblk, FiP, FiP, colsum_dx, Fin, 1, Fin, accumulate, st);
+    if (rc) return rc;
+  }
+  if (want_slope) {
+    hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(64), 0, st, part_sl, nblk, d_in_slope);
     GCL_CHECK_LAUNCH();
   }
   return GCL_OK;

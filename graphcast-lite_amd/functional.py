@@ -97,16 +97,15 @@ class MLPFn(torch.autograd.Function):
             inp = ctx.x2 if k == 0 else zs[k - 1]
             slope = None if k == 0 else params[3 * k - 1].detach()
             wi, bi = 3 * k, 3 * k + 1
-            if G.dst[wi] is not None or G.dst[bi] is not None:
-                dW = G.dst[wi] if G.dst[wi] is not None else torch.zeros_like(params[wi])
-                db = G.dst[bi]
-                hip.linear_bwd_dw(dz, inp, slope, dW, db, G.acc[wi])
+            dW = G.dst[wi] if G.dst[wi] is not None else torch.zeros_like(params[wi])
+            db = G.dst[bi]
             if k > 0:
-                si = 3 * k - 1
-                dsl = G.dst[si]
-                dz = hip.linear_bwd_dx(dz, W, inp, slope, dsl)
-            elif ctx.needs_input_grad[0]:
-                dx = hip.linear_bwd_dx(dz, W, None, None, None)
+                # one fused launch: dz_{k-1}, dW_k, db_k, d(slope_{k-1})
+                dz = hip.linear_bwd_all(dz, W, inp, slope, G.dst[3 * k - 1], dW, db, None, G.acc[wi])
+            else:
+                hip.linear_bwd_dw(dz, inp, None, dW, db, G.acc[wi])
+                if ctx.needs_input_grad[0]:
+                    dx = hip.linear_bwd_dx(dz, W, None, None, None)
         if dx is not None:
             dx = dx.view(dy.shape[:-1] + (dx.shape[-1],))
         return (dx, None, None, None) + G.out()
@@ -163,21 +162,22 @@ class GCNStackFn(torch.autograd.Function):
         dsl = G.dst[si] if params[si] is not None else None
         slope_t = params[si].detach() if params[si] is not None else None
         dx = None
+        if G.dst[2 * L - 1] is not None:  # bias of the last conv: its dp comes from outside this stack
+            hip.colsum(dp.reshape(B * n, -1), G.dst[2 * L - 1], G.acc[2 * L - 1])
         for k in range(L - 1, -1, -1):
             W = params[2 * k].detach()
-            wi, bi = 2 * k, 2 * k + 1
+            wi = 2 * k
             inp = (ctx.x3 if k == 0 else ps[k - 1]).view(B * n, -1)
-            slope = None if k == 0 else slope_t
-            if G.dst[bi] is not None:
-                hip.colsum(dp.reshape(B * n, -1), G.dst[bi], G.acc[bi])
-            dh = hip.aggregate(graph, dp, None, transpose=True)
-            dh2 = dh.view(B * n, -1)
-            if G.dst[wi] is not None:
-                hip.linear_bwd_dw(dh2, inp, slope, G.dst[wi], None, G.acc[wi])
+            dh2 = hip.aggregate(graph, dp, None, transpose=True).view(B * n, -1)
+            dW = G.dst[wi] if G.dst[wi] is not None else torch.zeros_like(params[wi])
             if k > 0:
-                dp = hip.linear_bwd_dx(dh2, W, inp, slope, dsl).view(B, n, -1)
-            elif ctx.needs_input_grad[0]:
-                dx = hip.linear_bwd_dx(dh2, W, None, None, None).view(B, n, -1)
+                # one fused launch: dp_{k-1} (with PReLU'), dW_k, d(slope) and the bias gradient of
+                # conv k-1 (= column sums of dp_{k-1})
+                dp = hip.linear_bwd_all(dh2, W, inp, slope_t, dsl, dW, None, G.dst[2 * k - 1], G.acc[wi]).view(B, n, -1)
+            else:
+                hip.linear_bwd_dw(dh2, inp, None, dW, None, G.acc[wi])
+                if ctx.needs_input_grad[0]:
+                    dx = hip.linear_bwd_dx(dh2, W, None, None, None).view(B, n, -1)
         if dx is not None and ctx.squeeze:
             dx = dx[0]
         return (dx, None, None, None, None, None) + G.out()

@@ -36,6 +36,9 @@ _SIGNATURES = {
     "gcl_linear_bwd_dx": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _sz, _vp]),
     "gcl_linear_bwd_dw": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "gcl_linear_bwd_ws_bytes": (_sz, [_i64, _i32, _i32]),
+    "gcl_linear_bwd_all": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32,
+                                     _i32, _vp, _sz, _vp]),
+    "gcl_linear_bwd_all_ws_bytes": (_sz, [_i64, _i32, _i32]),
     "gcl_aggregate": (C.c_int, [_vp, _i32, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "gcl_gat_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "gcl_gat_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
@@ -233,6 +236,19 @@ def linear_bwd_dw(dy, x, in_slope, dW, db, accumulate: bool):
 # bench.py sets this to {"graph": Graph, "events": []} to time the forward aggregation launches of
 # one graph with HIP events recorded on the launch stream (BENCH roofline line).
 AGG_PROFILE = None
+
+
+def linear_bwd_all(dy, W, x, in_slope, d_in_slope, dW, db, colsum_dx, accumulate: bool):
+    """dx (pre-activation gradient) + dW (+ db, slope gradient, column sums of dx) in one call."""
+    rows, Fout = dy.shape
+    Fin = W.shape[1]
+    dx = torch.empty(rows, Fin, dtype=torch.float32, device=dy.device)
+    nb = lib().gcl_linear_bwd_all_ws_bytes(rows, Fin, Fout)
+    ws = workspace(nb, dy.device)
+    _check(lib().gcl_linear_bwd_all(
+        _p(dy), _ld(dy), _p(W), _p(x), _ld(x), _p(in_slope), _p(d_in_slope), _p(dx), Fin, _p(dW), _p(db),
+        _p(colsum_dx), rows, Fin, Fout, 1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()))
+    return dx
 
 
 def aggregate(graph: Graph, h3, bias, transpose=False, out=None):

@@ -104,6 +104,15 @@ int gcl_linear_bwd_dw(const float* dy, int64_t lddy, const float* x, int64_t ldx
                       int32_t Fout, int32_t accumulate, void* ws, size_t ws_bytes,
                       gcl_stream_t stream);
 size_t gcl_linear_bwd_ws_bytes(int64_t rows, int32_t Fin, int32_t Fout);
+/* Whole backward of one dense transform in one call: dx (pre-activation gradient), dW, db (NULL: no
+ * bias), the slope gradient, and optionally colsum_dx[c] (+)= sum_r dx[r,c] (the bias gradient of
+ * the conv layer that produced x).  Uses ONE fused kernel (dY and x read once) when
+ * Fout <= 64, Fin <= 96 and rows are 16-B aligned, else the three separate kernels. */
+int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W, const float* x, int64_t ldx,
+                       const float* in_slope, float* d_in_slope, float* dx, int64_t lddx, float* dW,
+                       float* db, float* colsum_dx, int64_t rows, int32_t Fin, int32_t Fout,
+                       int32_t accumulate, void* ws, size_t ws_bytes, gcl_stream_t stream);
+size_t gcl_linear_bwd_all_ws_bytes(int64_t rows, int32_t Fin, int32_t Fout);
 
 /* ---------------------------------------------------------------------------------------------
  * Sparse aggregation over the CSR  y[b,i,:] = sum_{e in row i} w_e * h[b, col_e, :] (+ bias)

@@ -66,6 +66,32 @@ def test_linear_bwd(hip, rows, Fin, Fout):
     assert rel(dx2, dy @ W.detach()) < TOL
 
 
+@pytest.mark.parametrize("rows,Fin,Fout", [(1000, 64, 64), (4099, 48, 64), (300, 48, 48), (129, 72, 48), (5000, 64, 48),
+                                           (2000, 32, 32), (77, 48, 33), (700, 128, 128), (1, 64, 64)])
+@pytest.mark.parametrize("with_slope", [True, False])
+def test_linear_bwd_all(hip, rows, Fin, Fout, with_slope):
+    """Fused dX/dW/db/slope/column-sum backward (and its fallback for unsupported shapes)."""
+    x = rnd(rows, Fin, seed=1).requires_grad_()
+    W = rnd(Fout, Fin, seed=2, scale=0.2).requires_grad_()
+    b = rnd(Fout, seed=3).requires_grad_()
+    a = torch.tensor([0.25], requires_grad=True)
+    dy = rnd(rows, Fout, seed=4)
+    ((P.prelu(x, a) if with_slope else x) @ W.t() + b).backward(dy)
+    xd, Wd, dyd = x.detach().to(DEV), W.detach().to(DEV), dy.to(DEV)
+    ad = a.detach().to(DEV) if with_slope else None
+    da = torch.zeros(1, device=DEV) if with_slope else None
+    dW, db, cs = torch.ones(Fout, Fin, device=DEV), torch.ones(Fout, device=DEV), torch.ones(Fin, device=DEV)
+    dx = hip.linear_bwd_all(dyd, Wd, xd, ad, da, dW, db, cs, True)  # accumulate on top of ones
+    assert rel(dx, x.grad) < TOL
+    assert rel(dW - 1, W.grad) < 2e-5 and rel(db - 1, b.grad) < 2e-5
+    assert rel(cs - 1, x.grad.sum(0)) < 1e-4
+    if with_slope:
+        assert rel(da, a.grad) < 1e-4
+    dW2, db2 = torch.empty(Fout, Fin, device=DEV), torch.empty(Fout, device=DEV)
+    hip.linear_bwd_all(dyd, Wd, xd, ad, torch.zeros(1, device=DEV) if with_slope else None, dW2, db2, None, False)
+    assert rel(dW2, W.grad) < 2e-5 and rel(db2, b.grad) < 2e-5
+
+
 def test_linear_mfma_equals_valu(hip, monkeypatch):
     """The fp32 MFMA path and the plain VALU path of the same entry point agree (both fp32 FMA chains)."""
     import os

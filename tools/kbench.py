@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--config", default="baseline")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--only", default="", help="comma list of: copy,linear,agg,norm,misc (default all)")
     args = ap.parse_args()
     name = "wb2_512x256_19f_ar" if args.config.startswith("wb2") else args.config
     dev = torch.device("cuda:0")
@@ -57,14 +58,16 @@ def main():
     print(f"# {name}: B={B} G={G} M={M} n={n} F={F}")
     g = torch.Generator().manual_seed(0)
     rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    only = set(args.only.split(",")) if args.only else {"copy", "linear", "agg", "norm", "misc"}
 
     # stream copy ceiling
-    src, dst = rnd(64 * 1024 * 1024), torch.empty(64 * 1024 * 1024, device=dev)
-    us, mn = timeit(lambda: dst.copy_(src), args.iters)
-    row("torch copy 256 MiB (read+write)", us, mn, 2 * src.numel() * 4, 0)
+    if "copy" in only:
+      src, dst = rnd(64 * 1024 * 1024), torch.empty(64 * 1024 * 1024, device=dev)
+      us, mn = timeit(lambda: dst.copy_(src), args.iters)
+      row("torch copy 256 MiB (read+write)", us, mn, 2 * src.numel() * 4, 0)
 
     slope = torch.tensor([0.25], device=dev)
-    for rows, K, N, tag in ((B * n, F, F, "enc/dec"), (B * M, F, F, "mesh"), (B * n, cfg.data.num_features_used * 2 + 6, cfg.pipeline.encoder.mlp.mlp_hidden_dims[0], "mlp0")):
+    for rows, K, N, tag in () if "linear" not in only else ((B * n, F, F, "enc/dec"), (B * M, F, F, "mesh"), (B * n, cfg.data.num_features_used * 2 + 6, cfg.pipeline.encoder.mlp.mlp_hidden_dims[0], "mlp0")):
         x, W, b = rnd(rows, K), rnd(N, K) * 0.1, rnd(N)
         y = torch.empty(rows, N, device=dev)
         us, mn = timeit(lambda: hip.linear_fwd(x, W, b, slope, out=y), args.iters)
@@ -76,9 +79,12 @@ def main():
         dW, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
         us, mn = timeit(lambda: hip.linear_bwd_dw(dy, x, slope, dW, db, False), args.iters)
         row(f"linear_bwd_dw {tag} [{rows}x{N}]^T[{rows}x{K}]", us, mn, 4 * rows * (K + N), 2 * rows * K * N)
+        cs = torch.empty(K, device=dev)
+        us, mn = timeit(lambda: hip.linear_bwd_all(dy, W, x, slope, ds, dW, db, cs, False), args.iters)
+        row(f"linear_bwd_all {tag} (dx+dW+db+colsum)", us, mn, 4 * rows * (2 * K + N), 4 * rows * K * N)
 
     from graphcast_lite_amd.models import _graphs
-    for ei, nn_, tag in ((m.processing_graph, M, "mesh E_M"), (m.encoding_graph, n, "enc E_G2M"), (m.decoding_graph, n, "dec E_M2G")):
+    for ei, nn_, tag in () if "agg" not in only else ((m.processing_graph, M, "mesh E_M"), (m.encoding_graph, n, "enc E_G2M"), (m.decoding_graph, n, "dec E_M2G")):
         gr = _graphs.get(ei, nn_, hip.GRAPH_GCN)
         h, bias = rnd(B, nn_, F), rnd(F)
         out = torch.empty(B, nn_, F, device=dev)
@@ -88,6 +94,8 @@ def main():
         us, mn = timeit(lambda: hip.aggregate(gr, h, None, transpose=True, out=out), args.iters)
         row(f"aggregate bwd {tag} (transpose)", us, mn, B * per, 2 * B * gr.e * F)
 
+    if "norm" not in only:
+        return
     rows = B * n
     x, gm, bt = rnd(rows, F), rnd(F), rnd(F)
     us, mn = timeit(lambda: hip.layernorm_fwd(x, gm, bt), args.iters)
