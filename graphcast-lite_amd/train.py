@@ -155,6 +155,26 @@ class FlatParams:
         self.grad.zero_()
 
 
+def shard_batch(X, y, rank: int, world: int):
+    """Contiguous equal shards of the batch dimension: rank r owns samples
+    [r*B_local, (r+1)*B_local).  The global batch must divide evenly."""
+    B = X.shape[0]
+    if B % world != 0:
+        raise ValueError(f"global batch {B} is not divisible by world size {world}")
+    k = B // world
+    return X[rank * k:(rank + 1) * k], y[rank * k:(rank + 1) * k]
+
+
+def allreduce_gradients(flat: "FlatParams", world: int) -> float:
+    """C1, the only collective on the path: ONE all-reduce (sum) of the flat gradient bucket.
+    Returns the factor the optimiser must apply (1/world: the reference loss is a mean over the
+    batch, src/train.py:101-102, so the global gradient is the mean of the per-rank gradients
+    when every rank holds the same number of samples)."""
+    if world > 1:
+        dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM)
+    return 1.0 / world
+
+
 class FusedAdam:
     """torch.optim.Adam(lr, betas, eps, weight_decay=0) semantics over a FlatParams bucket."""
 
@@ -189,8 +209,6 @@ class TrainStep:
         loss = batch_loss(self.model, X, y, threshold, epoch, batch_num, self.lat_weights, self.ar_steps,
                           self.channel_mask, self.spatial_mask, None, None, self.use_residual)
         loss.backward()
-        if self.world > 1:
-            # C1: the only collective on the path - one flat bucket, sum over ranks, mean via grad_scale
-            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)
-        self.opt.step(grad_scale=1.0 / self.world)
+        scale = allreduce_gradients(self.flat, self.world)
+        self.opt.step(grad_scale=scale)
         return loss.detach()
