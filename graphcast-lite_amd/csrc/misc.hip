@@ -112,6 +112,40 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
   }
 }
 
+// dst[b,i,:] = a[b, map_a[i], :] if map_a[i] >= 0, else b_[b, map_b[i], :] if map_b[i] >= 0, else 0.
+// A source with batch stride 0 is broadcast over the batch.  sum_batch: dst[0,i,:] = sum_b a[b, map_a[i], :].
+// Row glue of the compact pipeline (stage split / concat of src/models.py:837-838,860-862 restricted
+// to the rows that matter); 16-B accesses, one row per F/4 lanes.
+__global__ __launch_bounds__(256) void gather2_kernel(const float* __restrict__ a, int64_t lda, int64_t bsa,
+                                                      const int32_t* __restrict__ map_a,
+                                                      const float* __restrict__ b_, int64_t ldb, int64_t bsb,
+                                                      const int32_t* __restrict__ map_b, float* __restrict__ dst,
+                                                      int64_t ldd, int64_t bsd, int32_t B, int32_t nd, int32_t F4,
+                                                      int32_t sum_batch) {
+  const int64_t total = (int64_t)(sum_batch ? 1 : B) * nd * F4;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c = (int)(idx % F4) * 4;
+    const int64_t bi = idx / F4;
+    const int i = (int)(bi % nd);
+    const int64_t b = bi / nd;
+    const int ja = map_a ? map_a[i] : i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sum_batch) {
+      if (ja >= 0)
+        for (int bb = 0; bb < B; ++bb) {
+          const float4 t = *reinterpret_cast<const float4*>(a + bb * bsa + (int64_t)ja * lda + c);
+          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+    } else if (ja >= 0) {
+      v = *reinterpret_cast<const float4*>(a + b * bsa + (int64_t)ja * lda + c);
+    } else if (b_ && map_b) {
+      const int jb = map_b[i];
+      if (jb >= 0) v = *reinterpret_cast<const float4*>(b_ + b * bsb + (int64_t)jb * ldb + c);
+    }
+    *reinterpret_cast<float4*>(dst + b * bsd + (int64_t)i * ldd + c) = v;
+  }
+}
+
 inline unsigned grid_for(int64_t total, int cap = 4096) {
   int64_t nb = gcl::cdiv(total > 0 ? total : 1, 256);
   return (unsigned)(nb > cap ? cap : nb);
@@ -178,6 +212,22 @@ extern "C" int gcl_copy_rows(const float* src, int64_t lds, int64_t bss, float* 
   const int64_t total = (int64_t)B * rows * (vec ? F / 4 : F);
   hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, src, lds, bss,
                      dst, ldd, bsd, B, rows, F, vec);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+extern "C" int gcl_gather2_rows(const float* a, int64_t lda, int64_t bsa, const int32_t* map_a, const float* b,
+                                int64_t ldb, int64_t bsb, const int32_t* map_b, float* dst, int64_t ldd, int64_t bsd,
+                                int32_t B, int32_t nd, int32_t F, int32_t sum_batch, gcl_stream_t stream) {
+  GCL_CHECK_ARG(a && dst, "gather2_rows: null argument");
+  GCL_CHECK_ARG(B > 0 && nd >= 0 && F > 0 && F % 4 == 0, "gather2_rows: F must be a positive multiple of 4 (F=%d)", F);
+  GCL_CHECK_ARG(lda % 4 == 0 && bsa % 4 == 0 && ldd % 4 == 0 && bsd % 4 == 0 && gcl::aligned16(a) && gcl::aligned16(dst) &&
+                    (!b || (ldb % 4 == 0 && bsb % 4 == 0 && gcl::aligned16(b))),
+                "gather2_rows: rows must be 16-B aligned");
+  if (nd == 0) return GCL_OK;
+  const int64_t total = (int64_t)(sum_batch ? 1 : B) * nd * (F / 4);
+  hipLaunchKernelGGL(gather2_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, a, lda, bsa, map_a,
+                     b, ldb, bsb, map_b, dst, ldd, bsd, B, nd, F / 4, sum_batch);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

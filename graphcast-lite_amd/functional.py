@@ -310,3 +310,36 @@ class WeightedMSEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return ctx.dd * g, None, None, None, None, None
+
+
+class Gather2Fn(torch.autograd.Function):
+    """Row gather from two sources with precomputed index maps (see hip.gather2_rows).
+    maps = (map_a, map_b, inv_a, inv_b): forward maps have length nd; inv_x[j] = destination row
+    fed by row j of source x, or -1.  A source with leading dimension 1 is broadcast over the
+    batch and receives the batch-summed gradient."""
+
+    @staticmethod
+    def forward(ctx, a, b, maps, nd: int, B: int):
+        map_a, map_b, inv_a, inv_b = maps
+        a3 = a.detach()
+        b3 = b.detach() if b is not None else None
+        if not a3.is_contiguous():
+            a3 = a3.contiguous()
+        if b3 is not None and not b3.is_contiguous():
+            b3 = b3.contiguous()
+        ctx.maps, ctx.B = maps, B
+        ctx.sa, ctx.sb = a3.shape, (b3.shape if b3 is not None else None)
+        return hip.gather2_rows(a3, map_a, b3, map_b, nd, B)
+
+    @staticmethod
+    def backward(ctx, g):
+        map_a, map_b, inv_a, inv_b = ctx.maps
+        g = g.contiguous()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            bc = ctx.sa[0] == 1 and ctx.B > 1
+            da = hip.gather2_rows(g, inv_a, None, None, ctx.sa[1], ctx.B, sum_batch=bc)
+        if ctx.sb is not None and ctx.needs_input_grad[1]:
+            bc = ctx.sb[0] == 1 and ctx.B > 1
+            db = hip.gather2_rows(g, inv_b, None, None, ctx.sb[1], ctx.B, sum_batch=bc)
+        return da, db, None, None, None

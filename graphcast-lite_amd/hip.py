@@ -62,6 +62,7 @@ _SIGNATURES = {
     "gcl_wmse_ws_bytes": (_sz, [_i32, _i32, _i32]),
     "gcl_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     "gcl_copy_rows": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "gcl_gather2_rows": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
 }
 
 
@@ -374,3 +375,22 @@ def copy_rows(src3, dst3):
     B, rows, F = src3.shape
     _check(lib().gcl_copy_rows(_p(src3), src3.stride(1), src3.stride(0), _p(dst3), dst3.stride(1), dst3.stride(0), B, rows, F, _stream()))
     return dst3
+
+
+def _pi(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()
+    return t.data_ptr()
+
+
+def gather2_rows(a3, map_a, b3, map_b, nd: int, B: int, sum_batch: bool = False):
+    """dst[b,i] = a3[b, map_a[i]] | b3[b or 0, map_b[i]] | 0   (see gcl_gather2_rows).
+    a3 / b3: [Ba, na, F] with unit channel stride; Ba == 1 broadcasts over B."""
+    F = a3.shape[-1]
+    out = torch.empty(1 if sum_batch else B, nd, F, dtype=torch.float32, device=a3.device)
+    bsa = a3.stride(0) if (a3.shape[0] > 1 or sum_batch) else 0
+    bsb = 0 if b3 is None else (b3.stride(0) if b3.shape[0] > 1 else 0)
+    _check(lib().gcl_gather2_rows(_p(a3), a3.stride(1), bsa, _pi(map_a), _p(b3), 0 if b3 is None else b3.stride(1),
+                                  bsb, _pi(map_b), _p(out), F, nd * F, B, nd, F, 1 if sum_batch else 0, _stream()))
+    return out

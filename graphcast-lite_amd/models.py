@@ -18,6 +18,7 @@ What is new relative to the reference (documented deviations, SURVEY.md Appendix
 Compute runs only on a GPU through `libgcl_hip.so`; there is no CPU path in this package.
 """
 import math
+import os
 from collections import OrderedDict
 from typing import Optional, Tuple
 
@@ -36,7 +37,7 @@ from .config import (
     PipelineConfig,
 )
 from .create_graphs import create_decoding_graph, create_encoding_graph, create_processing_graph
-from .functional import AssembleFn, GATLayerFn, GCNStackFn, LayerNormFn, MeanAggFn, MLPFn
+from .functional import AssembleFn, GATLayerFn, Gather2Fn, GCNStackFn, LayerNormFn, MeanAggFn, MLPFn
 from .mesh import get_hierarchy_of_triangular_meshes_for_sphere, get_mesh_lat_long, prune_mesh_to_region
 
 
@@ -399,7 +400,95 @@ class WeatherPrediction(nn.Module):
         """`src/models.py:776-806` in one kernel: [grid dyn | grid static ; 0 | mesh static]."""
         return AssembleFn.apply(grid_node_features, self.init_grid_features, self.init_mesh_features)
 
+    # --------------------------------------------------------------------------------------------
+    # Compact pipeline: the same arithmetic per row, on fewer rows.
+    #  * Encoder: a mesh row without grid in-edges only ever sees its own self-loop and its input
+    #    is [0 | static] (src/models.py:792-801), so its whole encoder output is batch-invariant:
+    #    those rows (8302 of 10242 at 64x32) are computed ONCE per forward instead of per sample.
+    #  * Decoder: only grid rows are returned (src/models.py:870-872) and mesh rows only carry
+    #    self-loops there, so mesh rows that send to no grid node are dead and are dropped.
+    # Sub-graphs keep every in-edge (and its order) of every kept row and the in-degree of every
+    # sender, so gcn_norm weights and summation order per row are unchanged (SURVEY.md App. B.7).
+    # --------------------------------------------------------------------------------------------
+    def _compact_eligible(self) -> bool:
+        if os.environ.get("GCL_NO_COMPACT", "0") not in ("0", ""):
+            return False
+        ok = lambda m: m.graph_layer.layer_type == GraphLayerType.ConvGCN
+        return ok(self.encoder) and ok(self.decoder) and getattr(self, "compact", True)
+
+    def _compact_setup(self, device):
+        G, M = self._num_grid_nodes, self._num_mesh_nodes
+        enc, dec = self.encoding_graph.cpu(), self.decoding_graph.cpu()
+        i32 = lambda t: t.to(torch.int32).contiguous().to(device)
+        md = torch.unique(enc[1]) - G                       # mesh rows with grid in-edges (ascending)
+        is_dep = torch.zeros(M, dtype=torch.bool)
+        is_dep[md] = True
+        mi = torch.nonzero(~is_dep).flatten()               # batch-invariant mesh rows
+        used = torch.unique(dec[0]) - G                     # mesh rows some grid node reads in the decoder
+        Md, Mi, U = md.numel(), mi.numel(), used.numel()
+        remap_e = torch.full((G + M,), -1, dtype=torch.int64)
+        remap_e[:G] = torch.arange(G)
+        remap_e[G + md] = G + torch.arange(Md)
+        remap_d = torch.full((G + M,), -1, dtype=torch.int64)
+        remap_d[:G] = torch.arange(G)
+        remap_d[G + used] = G + torch.arange(U)
+        c = type("Compact", (), {})()
+        c.Md, c.Mi, c.U = Md, Mi, U
+        c.enc_graph = remap_e[enc].contiguous().to(device)
+        c.dec_graph = remap_d[dec].contiguous().to(device)
+        c.empty_graph = torch.zeros(2, 0, dtype=torch.int64, device=device)
+        c.mstat_dep = self.init_mesh_features[md.to(self.init_mesh_features.device)].contiguous()
+        Cdyn = self.total_feature_size
+        inv_stat = self.init_mesh_features[mi.to(self.init_mesh_features.device)]
+        c.x_inv = torch.cat([torch.zeros(Mi, Cdyn, device=device), inv_stat.to(device)], dim=1).unsqueeze(0).contiguous()
+        # mesh latents [M] <- encoder compact output [G+Md] (a) | invariant rows [Mi] (b)
+        map_a = torch.full((M,), -1, dtype=torch.int64)
+        map_a[md] = G + torch.arange(Md)
+        map_b = torch.full((M,), -1, dtype=torch.int64)
+        map_b[mi] = torch.arange(Mi)
+        inv_a = torch.full((G + Md,), -1, dtype=torch.int64)
+        inv_a[G:] = md
+        c.maps_mesh = (i32(map_a), i32(map_b), i32(inv_a), i32(mi))
+        # decoder input [G+U] <- encoder compact output (a: grid rows) | processed mesh [M] (b)
+        dmap_a = torch.full((G + U,), -1, dtype=torch.int64)
+        dmap_a[:G] = torch.arange(G)
+        dmap_b = torch.full((G + U,), -1, dtype=torch.int64)
+        dmap_b[G:] = used
+        dinv_a = torch.full((G + Md,), -1, dtype=torch.int64)
+        dinv_a[:G] = torch.arange(G)
+        dinv_b = torch.full((M,), -1, dtype=torch.int64)
+        dinv_b[used] = G + torch.arange(U)
+        c.maps_dec = (i32(dmap_a), i32(dmap_b), i32(dinv_a), i32(dinv_b))
+        self._compact = c
+        return c
+
+    def _forward_compact(self, X: torch.Tensor, attention_threshold=0.0, **kwargs):
+        G, M = self._num_grid_nodes, self._num_mesh_nodes
+        squeeze = X.dim() == 2 or (X.dim() == 3 and X.shape[0] == 1)
+        X3 = X if X.dim() == 3 else X.unsqueeze(0)
+        B = X3.shape[0]
+        c = getattr(self, "_compact", None) or self._compact_setup(X3.device)
+        x_c = AssembleFn.apply(X3, self.init_grid_features, c.mstat_dep)           # [B, G+Md, C]
+        enc_c = self.encoder.forward(X=x_c, edge_index=c.enc_graph)                 # [B, G+Md, D]
+        inv = self.encoder.forward(X=c.x_inv, edge_index=c.empty_graph) if c.Mi > 0 else None  # [1, Mi, D]
+        mesh_lat = Gather2Fn.apply(enc_c, inv, c.maps_mesh, M, B)                   # [B, M, D]
+        if self.using_sparse_gat:
+            processed, new_edge_index = self.processor.forward(
+                X=mesh_lat, edge_index=self.processing_graph, attention_threshold=attention_threshold, **kwargs)
+            self.processing_graph = new_edge_index
+        else:
+            processed = self.processor.forward(X=mesh_lat, edge_index=self.processing_graph,
+                                               attention_threshold=attention_threshold)
+        dec_in = Gather2Fn.apply(enc_c, processed, c.maps_dec, G + c.U, B)          # [B, G+U, D]
+        decoded = self.decoder.forward(X=dec_in, edge_index=c.dec_graph)
+        out, grid_lat = decoded[:, :G, :], enc_c[:, :G, :]
+        if squeeze:
+            return out[0], grid_lat[0], processed[0]
+        return out, grid_lat, processed
+
     def forward_with_latents(self, X: torch.Tensor, attention_threshold=0.0, **kwargs):
+        if self._compact_eligible():
+            return self._forward_compact(X, attention_threshold, **kwargs)
         G = self._num_grid_nodes
         if X.dim() == 3 and X.shape[0] == 1:
             X = X.squeeze(0)  # reference: X.squeeze() with batch 1 (src/models.py:822)

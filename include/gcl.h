@@ -221,6 +221,15 @@ int gcl_adam_step(float* p, const float* g, float* m, float* v, int64_t count, f
 int gcl_copy_rows(const float* src, int64_t lds, int64_t bss, float* dst, int64_t ldd, int64_t bsd,
                   int32_t B, int32_t rows, int32_t F, gcl_stream_t stream);
 
+/* Row gather from up to two sources (stage glue of src/models.py:837-838,860-862 restricted to the
+ * rows that matter):  dst[b,i,:] = a[b, map_a[i], :] if map_a[i] >= 0 (map_a NULL = identity), else
+ * b[b, map_b[i], :] if map_b[i] >= 0, else 0.  A source with batch stride 0 is broadcast.
+ * sum_batch != 0:  dst[0,i,:] = sum_b a[b, map_a[i], :]  (gradient of a broadcast source).
+ * Maps are int32 device arrays of length nd; F % 4 == 0 and 16-B aligned rows. */
+int gcl_gather2_rows(const float* a, int64_t lda, int64_t bsa, const int32_t* map_a, const float* b,
+                     int64_t ldb, int64_t bsb, const int32_t* map_b, float* dst, int64_t ldd, int64_t bsd,
+                     int32_t B, int32_t nd, int32_t F, int32_t sum_batch, gcl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
