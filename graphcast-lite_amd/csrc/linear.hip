@@ -653,7 +653,8 @@ __global__ __launch_bounds__(256, 1) void linear_bwd_fused_kernel(
   }
 
   // ---- per-block partials ----
-  float* out = part_dw + (size_t)blockIdx.x * FoP * FiP;
+  constexpr size_t REC = (size_t)FoP * FiP + FoP + FiP;  // per-block record: [dW | db | colsum]
+  float* out = part_dw + (size_t)blockIdx.x * REC;
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
     const int tix = wave + 4 * q;
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(256, 1) void linear_bwd_fused_kernel(
       for (int r = 0; r < 16; ++r) out[(size_t)(so * 32 + d_row(r, lane)) * FiP + sc * 32 + li] = dw[q][r];
       if (part_db && sc == 0) {
         const float d = dbacc[q] + __shfl_xor(dbacc[q], 32, 64);
-        if (lane < 32) part_db[(size_t)blockIdx.x * FoP + so * 32 + lane] = d;
+        if (lane < 32) part_db[(size_t)blockIdx.x * REC + so * 32 + lane] = d;
       }
     }
   }
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(256, 1) void linear_bwd_fused_kernel(
   __syncthreads();
   if (part_cs)
     for (int c = tid; c < FiP; c += 256)
-      part_cs[(size_t)blockIdx.x * FiP + c] = (red[c] + red[FiP + c]) + (red[2 * FiP + c] + red[3 * FiP + c]);
+      part_cs[(size_t)blockIdx.x * REC + c] = (red[c] + red[FiP + c]) + (red[2 * FiP + c] + red[3 * FiP + c]);
   if (part_slope && tid == 0) part_slope[blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
 }
 
@@ -712,6 +713,47 @@ __global__ void reduce_scalar_kernel(const double* __restrict__ part, int32_t np
   for (int p = threadIdx.x; p < nparts; p += 64) s += part[p];
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if (threadIdx.x == 0) *out += (float)s;
+}
+
+// Up to 3 output segments reduced in ONE launch: segment g covers `count[g]` consecutive floats of
+// every partial record starting at offset `poff[g]`; element e of it goes to out[g][(e / pld) * ldo
+// + e % pld] when (e % pld) < cols (partial tiles are padded to pld columns).  16 threads split
+// the partial records of one element, combined through LDS in a fixed order.
+struct RedSeg {
+  float* out;
+  int32_t poff, count, pld, cols, ldo;
+};
+__global__ __launch_bounds__(256) void reduce_multi_kernel(const float* __restrict__ part, int32_t nparts,
+                                                           int64_t pstride, RedSeg s0, RedSeg s1, RedSeg s2,
+                                                           int32_t accumulate) {
+  __shared__ float red[16][17];
+  const int e16 = threadIdx.x & 15, g = threadIdx.x >> 4;
+  int idx = blockIdx.x * 16 + e16;
+  RedSeg sg = s0;
+  if (idx >= s0.count) {
+    idx -= s0.count;
+    sg = s1;
+    if (idx >= s1.count) {
+      idx -= s1.count;
+      sg = s2;
+    }
+  }
+  const bool ok = idx < sg.count;
+  float s = 0.f;
+  if (ok)
+    for (int p = g; p < nparts; p += 16) s += part[(size_t)p * pstride + sg.poff + idx];
+  red[g][e16] = s;
+  __syncthreads();
+  if (g == 0 && ok) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += red[q][e16];
+    const int i = idx / sg.pld, j = idx - i * sg.pld;
+    if (j < sg.cols) {
+      float* o = sg.out + (size_t)i * sg.ldo + j;
+      *o = accumulate ? *o + tot : tot;
+    }
+  }
 }
 
 }  // namespace
@@ -985,10 +1027,11 @@ extern "C" int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W,
   const int FoP = NO * 32, FiP = NC * 32;
   const int64_t ntiles = gcl::cdiv(rows, 128);
   const int nblk = (int)(ntiles < gcl::kNumCU ? ntiles : gcl::kNumCU);
+  const size_t rec_f = (size_t)FoP * FiP + FoP + FiP;  // floats per block record
   float* part_dw = (float*)ws;
-  float* part_db = part_dw + (size_t)gcl::kNumCU * FoP * FiP;
-  float* part_cs = part_db + (size_t)gcl::kNumCU * FoP;
-  double* part_sl = (double*)(((uintptr_t)(part_cs + (size_t)gcl::kNumCU * FiP) + 15) & ~(uintptr_t)15);
+  float* part_db = part_dw + (size_t)FoP * FiP;
+  float* part_cs = part_db + FoP;
+  double* part_sl = (double*)(((uintptr_t)(part_dw + (size_t)gcl::kNumCU * rec_f) + 15) & ~(uintptr_t)15);
   const size_t lds = ((size_t)FiP * (FoP + 2) + 128 * (size_t)(FoP + 2) + 128 * (size_t)FiP) * sizeof(float);
   const bool want_slope = in_slope && d_in_slope;
 #define GCL_FB(NO_, NC_)                                                                                          \
@@ -1007,15 +1050,16 @@ extern "C" int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W,
   else GCL_FB(2, 3);
 #undef GCL_FB
   GCL_CHECK_LAUNCH();
-  int rc = gcl::launch_reduce_parts(part_dw, nblk, (int64_t)FoP * FiP, FiP, dW, Fin, Fout, Fin, accumulate, st);
-  if (rc) return rc;
-  if (db) {
-    rc = gcl::launch_reduce_parts(part_db, nblk, FoP, FoP, db, Fout, 1, Fout, accumulate, st);
-    if (rc) return rc;
-  }
-  if (colsum_dx) {
-    rc = gcl::launch_reduce_parts(part_cs, nblk, FiP, FiP, colsum_dx, Fin, 1, Fin, accumulate, st);
-    if (rc) return rc;
+  {
+    // per-block record: [dW tile FoP*FiP | db FoP | colsum FiP]; one launch reduces all three
+    const int64_t rec = (int64_t)FoP * FiP + FoP + FiP;
+    RedSeg s0{dW, 0, Fout * FiP, FiP, Fin, Fin};
+    RedSeg s1{db, FoP * FiP, db ? Fout : 0, FoP, Fout, 0};
+    RedSeg s2{colsum_dx, FoP * FiP + FoP, colsum_dx ? Fin : 0, FiP, Fin, 0};
+    const int total = s0.count + s1.count + s2.count;
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)gcl::cdiv(total, 16)), dim3(256), 0, st, part_dw, nblk, rec,
+                       s0, s1, s2, accumulate);
+    GCL_CHECK_LAUNCH();
   }
   if (want_slope) {
     hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(64), 0, st, part_sl, nblk, d_in_slope);
