@@ -220,10 +220,9 @@ __global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel
         for (int r = 0; r < 16; ++r) {
           const int rr = wave * 32 + d_row(r, lane);
           float v = acc[s][r];
-          if (has_z && zv[r] <= 0.f) {
-            slope_acc += (double)(v * zv[r]);
-            v *= zs;
-          }
+          const bool neg = has_z && (zv[r] <= 0.f);
+          slope_acc += neg ? (double)(v * zv[r]) : 0.0;
+          v = neg ? v * zs : v;
           buf_st1(ry, jok ? (unsigned)((rr * ldy + j) * 4) : kOOB, v);
         }
       } else {
@@ -592,22 +591,22 @@ __global__ __launch_bounds__(256, 1) void linear_bwd_fused_kernel(
         for (int s2 = 0; s2 < NC; ++s2) b_c[s2] = b_n[s2];
       }
     }
-    // epilogue: PReLU' from the LDS copy of P, slope / column-sum accumulation, unconditional stores
+    // epilogue: PReLU' from the LDS copy of P, slope / column-sum accumulation; branch-free (all
+    // 16 Z reads of a slab are issued together, masks are selects, stores are unconditional)
 #pragma unroll
     for (int s2 = 0; s2 < NC; ++s2) {
       const int j = s2 * 32 + li;
       const bool jok = j < Fin;
+      float zv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zv[r] = Pl[(wave * 32 + d_row(r, lane)) * FiP + j];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rr = wave * 32 + d_row(r, lane);
         float v = acc[s2][r];
-        if (act) {
-          const float z = Pl[rr * FiP + j];
-          if (z <= 0.f) {
-            slope_acc += (double)(v * z);
-            v *= slope;
-          }
-        }
+        const bool neg = act && (zv[r] <= 0.f);
+        slope_acc += neg ? (double)(v * zv[r]) : 0.0;
+        v = neg ? v * slope : v;
         cs[s2] += v;
         buf_st1(rx, jok ? (unsigned)((rr * lddx + j) * 4) : kOOB, v);
       }
@@ -761,8 +760,11 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const float* __restri
 namespace gcl {
 int launch_reduce_parts(const float* part, int nparts, int64_t pstride, int pld, float* out, int ldo, int R, int C,
                         int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv((int64_t)R * C, 64)), dim3(256), 0, st, part, nparts,
-                     pstride, pld, out, ldo, R, C, accumulate);
+  // one segment of the 16-way reducer: R rows of pld (padded) columns, C of them valid
+  RedSeg s0{out, 0, R * pld, pld, C, ldo};
+  RedSeg none{nullptr, 0, 0, 1, 0, 0};
+  hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)cdiv((int64_t)R * pld, 16)), dim3(256), 0, st, part, nparts,
+                     pstride, s0, none, none, accumulate);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
@@ -974,15 +976,10 @@ extern "C" int gcl_linear_bwd_dw(const float* dy, int64_t lddy, const float* x, 
 #undef GCL_DW2
 #undef GCL_DW3
   GCL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)gcl::cdiv((int64_t)Fout * Fin, 64)), dim3(256), 0, st, part,
-                     (int)nblk, (int64_t)FoutP * FinP, FinP, dW, Fin, Fout, Fin, accumulate);
-  GCL_CHECK_LAUNCH();
-  if (db) {
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)gcl::cdiv(Fout, 64)), dim3(256), 0, st, dbpart, (int)nblk,
-                       (int64_t)FoutP, FoutP, db, Fout, 1, Fout, accumulate);
-    GCL_CHECK_LAUNCH();
-  }
-  return GCL_OK;
+  int rc = gcl::launch_reduce_parts(part, (int)nblk, (int64_t)FoutP * FinP, FinP, dW, Fin, Fout, Fin, accumulate, st);
+  if (rc) return rc;
+  if (db) rc = gcl::launch_reduce_parts(dbpart, (int)nblk, (int64_t)FoutP, FoutP, db, Fout, 1, Fout, accumulate, st);
+  return rc;
 }
 
 // Fused path geometry / workspace (see linear_bwd_fused_kernel)
