@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--config", default="baseline",
                     choices=["baseline", "attention", "attention_h4", "sparse_attention", "wb2_512x256_19f_ar"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a captured hipGraph (1 GPU). Off by default: launches inside a "
+                         "replayed graph cannot be bracketed by HIP events, which the roofline line needs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,7 +122,8 @@ def main():
     G, M = model._num_grid_nodes, model._num_mesh_nodes
     X, y = synthetic_batch(cfg, G, B, seed=1234 + rank)  # every rank its own samples
     X, y = X.to(dev), y.to(dev)                           # resident in HBM before the timed region
-    step = TrainStep(model, lr=1e-3, lat_weights=get_lat_weights(grid[0], grid[1], dev), world_size=world)
+    step = TrainStep(model, lr=1e-3, lat_weights=get_lat_weights(grid[0], grid[1], dev), world_size=world,
+                     use_graph=bool(args.graph) and world == 1)
 
     for _ in range(args.warmup):
         loss = step(X, y)
@@ -167,7 +171,8 @@ def main():
             "config": {"workload": f"{args.config} (BASELINE.json configs[1] family): grid {grid[1]}x{grid[0]}, "
                                    f"G={G}, mesh M={M}, {cfg.data.num_features_used} feat, obs 2, AR 1, "
                                    f"fwd+loss+bwd+Adam", "batch_per_gpu": B, "global_batch": B * args.gpus,
-                       "parallelism": f"dp{args.gpus}", "final_loss": final_loss},
+                       "parallelism": f"dp{args.gpus}", "final_loss": final_loss,
+                       "launch_mode": "hipGraph replay" if step.use_graph else "eager"},
             "roofline": roof,
         }
         if args.gpus == 1 and not args.no_cpu_baseline:

@@ -842,8 +842,8 @@ int launch_linear(const float* X, int64_t ldx, const float* in_slope, const floa
 #define GCL_LIN3(NS_, KT_, V_)                                                                                    \
   do {                                                                                                            \
     auto kern = linear_mfma_kernel<NS_, EPI, KT_, V_>;                                                            \
-    if (g.lds > 64 * 1024)                                                                                        \
-      GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds)); \
+    { static bool lds_set = false;                                                                          \
+      if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
     hipLaunchKernelGGL(kern, dim3(g.grid), dim3(g.waves * 64), g.lds, st, X, ldx, in_slope, W, ldw, trans, bias,  \
                        Y, ldy, rows, K, N, Z, ldz, z_slope, slope_part);                                          \
   } while (0)
@@ -947,8 +947,8 @@ extern "C" int gcl_linear_bwd_dw(const float* dy, int64_t lddy, const float* x, 
 #define GCL_DW3(NO_, NC_, V_)                                                                                     \
   do {                                                                                                            \
     auto kern = dw_mfma_kernel<NO_, NC_, V_>;                                                                     \
-    if (lds > 64 * 1024)                                                                                          \
-      GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    { static bool lds_set = false;                                                                          \
+      if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, dy, lddy, x, ldx, in_slope, part,          \
                        db ? dbpart : nullptr, rows, Fin, Fout, rpb);                                              \
   } while (0)
@@ -1034,7 +1034,8 @@ extern "C" int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W,
 #define GCL_FB(NO_, NC_)                                                                                          \
   do {                                                                                                            \
     auto kern = linear_bwd_fused_kernel<NO_, NC_>;                                                                \
-    GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+    { static bool lds_set = false;                                                                          \
+      if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, dy, lddy, W, x, ldx, in_slope, dx, lddx, rows, Fin,  \
                        Fout, part_dw, db ? part_db : nullptr, colsum_dx ? part_cs : nullptr,                      \
                        want_slope ? part_sl : nullptr);                                                           \

@@ -86,6 +86,32 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// Device-resident step counter: lets a captured hipGraph replay the optimiser without any
+// step-dependent host scalar baked into it.  state[0] = step (as float bits of an int), bc = {bc1, sqrt(bc2)}.
+__global__ void adam_tick_kernel(int32_t* __restrict__ step, float* __restrict__ bc, float b1, float b2) {
+  const int t = *step + 1;
+  *step = t;
+  bc[0] = (float)(1.0 - pow((double)b1, (double)t));
+  bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+}
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, int64_t count,
+                                                       float lr, float b1, float b2, float eps, float wd,
+                                                       const float* __restrict__ bc, float gscale) {
+  const float bc1 = bc[0], bc2_sqrt = bc[1];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    float gi = g[i] * gscale;
+    if (wd != 0.f) gi += wd * p[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
 __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, int64_t lds, int64_t bss,
                                                         float* __restrict__ dst, int64_t ldd, int64_t bsd, int32_t B,
                                                         int32_t rows, int32_t F, int32_t vec) {
@@ -228,6 +254,20 @@ extern "C" int gcl_gather2_rows(const float* a, int64_t lda, int64_t bsa, const 
   const int64_t total = (int64_t)(sum_batch ? 1 : B) * nd * (F / 4);
   hipLaunchKernelGGL(gather2_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, a, lda, bsa, map_a,
                      b, ldb, bsb, map_b, dst, ldd, bsd, B, nd, F / 4, sum_batch);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+extern "C" int gcl_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, int32_t* step_dev, float* bc_dev,
+                                 float grad_scale, gcl_stream_t stream) {
+  GCL_CHECK_ARG(p && g && m && v && step_dev && bc_dev, "adam_dev: null argument");
+  GCL_CHECK_ARG(count >= 0, "adam_dev: bad count");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step_dev, bc_dev, beta1, beta2);
+  if (count > 0)
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(count, 1024)), dim3(256), 0, st, p, g, m, v, count, lr, beta1,
+                       beta2, eps, weight_decay, bc_dev, grad_scale);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -61,6 +61,7 @@ _SIGNATURES = {
                                    _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "gcl_wmse_ws_bytes": (_sz, [_i32, _i32, _i32]),
     "gcl_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
+    "gcl_adam_step_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _vp]),
     "gcl_copy_rows": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "gcl_gather2_rows": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
 }
@@ -369,6 +370,12 @@ def wmse_fwd_bwd(delta3, x_last3, y3, node_w, chan_w, inv_wsum, grad_scale, want
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     _check(lib().gcl_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, int(step),
                                float(grad_scale), _stream()))
+
+
+def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step_dev, bc_dev, grad_scale=1.0):
+    assert step_dev.dtype == torch.int32 and step_dev.is_cuda
+    _check(lib().gcl_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay,
+                                   step_dev.data_ptr(), _p(bc_dev), float(grad_scale), _stream()))
 
 
 def copy_rows(src3, dst3):

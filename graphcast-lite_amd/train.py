@@ -6,6 +6,7 @@
 Adam-state buffer, gradients accumulated in place by the backward kernels, ONE RCCL all-reduce of
 the flat gradient bucket per optimiser step, one fused Adam launch.
 """
+import os
 from typing import List, Optional
 
 import torch
@@ -41,9 +42,18 @@ def combine_spatial_masks(*masks):
     return out
 
 
+_lw_cache = {}
+
+
 def _loss_weights(G: int, C: int, lat_weights, channel_mask, spatial_mask, device):
-    """Per-node and per-channel factors of the reference's broadcast weight tensor and 1/sum(w)
-    for ONE sample (the caller multiplies by the batch size)."""
+    """Per-node and per-channel factors of the reference's broadcast weight tensor and sum(w) for
+    ONE sample (the caller multiplies by the batch size).  Cached per mask set: building it needs a
+    host read-back, which must not happen every step (nor inside a hipGraph capture)."""
+    key = (G, C, str(device)) + tuple((id(t), t._version) if t is not None else None
+                                      for t in (lat_weights, channel_mask, spatial_mask))
+    hit = _lw_cache.get(key)
+    if hit is not None:
+        return hit[0]
     node_w = None
     for t in (spatial_mask, lat_weights):
         if t is not None:
@@ -52,8 +62,12 @@ def _loss_weights(G: int, C: int, lat_weights, channel_mask, spatial_mask, devic
     chan_w = channel_mask.reshape(-1).to(device=device, dtype=torch.float32) if channel_mask is not None else None
     s_node = node_w.double().sum().item() if node_w is not None else float(G)
     s_chan = chan_w.double().sum().item() if chan_w is not None else float(C)
-    return (node_w.contiguous() if node_w is not None else None,
-            chan_w.contiguous() if chan_w is not None else None, s_node * s_chan)
+    out = (node_w.contiguous() if node_w is not None else None,
+           chan_w.contiguous() if chan_w is not None else None, s_node * s_chan)
+    if len(_lw_cache) > 64:
+        _lw_cache.clear()
+    _lw_cache[key] = (out, lat_weights, channel_mask, spatial_mask)  # keep the keys' tensors alive
+    return out
 
 
 def weighted_mse_loss(pred, target, lat_weights=None, channel_mask=None, spatial_mask=None, x_last=None):
@@ -176,35 +190,49 @@ def allreduce_gradients(flat: "FlatParams", world: int) -> float:
 
 
 class FusedAdam:
-    """torch.optim.Adam(lr, betas, eps, weight_decay=0) semantics over a FlatParams bucket."""
+    """torch.optim.Adam(lr, betas, eps, weight_decay=0) semantics over a FlatParams bucket.
+    The step counter lives on the device so the update can sit inside a captured hipGraph."""
 
     def __init__(self, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.flat, self.lr, self.betas, self.eps, self.wd = flat, lr, betas, eps, weight_decay
         self.m = torch.zeros_like(flat.flat)
         self.v = torch.zeros_like(flat.flat)
-        self.t = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=flat.flat.device)
+        self.bc_dev = torch.zeros(2, dtype=torch.float32, device=flat.flat.device)
+
+    @property
+    def t(self) -> int:
+        return int(self.step_dev.item())
 
     def step(self, grad_scale: float = 1.0):
-        self.t += 1
-        hip.adam_step(self.flat.flat, self.flat.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1],
-                      self.eps, self.wd, self.t, grad_scale)
+        hip.adam_step_dev(self.flat.flat, self.flat.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1],
+                          self.eps, self.wd, self.step_dev, self.bc_dev, grad_scale)
 
     def zero_grad(self):
         self.flat.zero_grad()
 
 
 class TrainStep:
-    """One optimiser step on a local batch: forward, loss, backward, [all-reduce], Adam."""
+    """One optimiser step on a local batch: forward, loss, backward, [all-reduce], Adam.
+
+    With `use_graph` (default, single GPU only) the whole step - ~160 kernel launches - is captured
+    once into a hipGraph (via torch.cuda.CUDAGraph on the stream the kernels are enqueued on) and
+    replayed; inputs are copied into static buffers first.  Multi-GPU keeps eager launches so the
+    RCCL all-reduce stays an ordinary stream operation between backward and Adam."""
 
     def __init__(self, model, lr=1e-3, lat_weights=None, channel_mask=None, spatial_mask=None, use_residual=True,
-                 ar_steps=1, world_size=1):
+                 ar_steps=1, world_size=1, use_graph=None):
         self.model = model
         self.flat = FlatParams(model)
         self.opt = FusedAdam(self.flat, lr=lr)
         self.lat_weights, self.channel_mask, self.spatial_mask = lat_weights, channel_mask, spatial_mask
         self.use_residual, self.ar_steps, self.world = use_residual, ar_steps, world_size
+        if use_graph is None:
+            use_graph = world_size == 1 and os.environ.get("GCL_NO_GRAPH", "0") in ("0", "")
+        self.use_graph = bool(use_graph) and not getattr(model, "using_sparse_gat", False)
+        self._graph, self._sX, self._sy, self._sloss, self._eager_calls = None, None, None, None, 0
 
-    def __call__(self, X, y, threshold=0.0, epoch=0, batch_num=1):
+    def _eager(self, X, y, threshold=0.0, epoch=0, batch_num=1):
         self.flat.zero_grad()
         loss = batch_loss(self.model, X, y, threshold, epoch, batch_num, self.lat_weights, self.ar_steps,
                           self.channel_mask, self.spatial_mask, None, None, self.use_residual)
@@ -212,3 +240,36 @@ class TrainStep:
         scale = allreduce_gradients(self.flat, self.world)
         self.opt.step(grad_scale=scale)
         return loss.detach()
+
+    def _capture(self, X, y):
+        self._sX, self._sy = X.clone(), y.clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._sloss = self._eager(self._sX, self._sy)
+        self._graph = g
+
+    def __call__(self, X, y, threshold=0.0, epoch=0, batch_num=1):
+        if not self.use_graph:
+            return self._eager(X, y, threshold, epoch, batch_num)
+        if self._graph is None:
+            # a few eager steps first: workspaces, CSR handles and kernel attributes get set up
+            # outside the capture
+            if self._eager_calls < 2:
+                self._eager_calls += 1
+                return self._eager(X, y, threshold, epoch, batch_num)
+            try:
+                self._capture(X, y)
+            except Exception as e:  # capture is an optimisation, never a requirement
+                print(f"[TrainStep] hipGraph capture unavailable ({type(e).__name__}: {str(e)[:300]}); staying eager",
+                      flush=True)
+                self.use_graph, self._graph = False, None
+                torch.cuda.synchronize()
+                return self._eager(X, y, threshold, epoch, batch_num)
+            self._graph.replay()  # capture only records; the first replay performs this step
+            return self._sloss.detach()
+        if X.shape != self._sX.shape:
+            return self._eager(X, y, threshold, epoch, batch_num)
+        self._sX.copy_(X)
+        self._sy.copy_(y)
+        self._graph.replay()
+        return self._sloss.detach()

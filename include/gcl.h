@@ -217,6 +217,13 @@ int gcl_adam_step(float* p, const float* g, float* m, float* v, int64_t count, f
                   float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
                   gcl_stream_t stream);
 
+/* Same update with the step counter kept ON THE DEVICE (step_dev: one int32, incremented by the
+ * call; bc_dev: two floats of scratch), so a captured hipGraph of the training step can be replayed
+ * without any step-dependent host value baked into it. */
+int gcl_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int32_t* step_dev, float* bc_dev,
+                      float grad_scale, gcl_stream_t stream);
+
 /* Strided row copy  dst[b, i, 0:F] = src[b, i, 0:F]  (stage glue: src/models.py:837-838,860-862). */
 int gcl_copy_rows(const float* src, int64_t lds, int64_t bss, float* dst, int64_t ldd, int64_t bsd,
                   int32_t B, int32_t rows, int32_t F, gcl_stream_t stream);

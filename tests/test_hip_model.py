@@ -171,6 +171,28 @@ def test_train_step_matches_torch_adam_on_oracle():
         assert rel(p, od[n_]) < 1e-4, n_
 
 
+def test_graph_captured_step_equals_eager():
+    """TrainStep replayed from a captured hipGraph follows the same trajectory as eager launches."""
+    from graphcast_lite_amd.train import TrainStep, get_lat_weights
+
+    cfg, m1, _ = make_pair("baseline", [1, 2])
+    _, m2, _ = make_pair("baseline", [1, 2])
+    X, y = data(cfg, m1._num_grid_nodes, 4)
+    Xd, yd = X.to(DEV), y.to(DEV)
+    lw = get_lat_weights(32, 64, DEV)
+    s1 = TrainStep(m1, lr=1e-3, lat_weights=lw, use_graph=True)
+    s2 = TrainStep(m2, lr=1e-3, lat_weights=lw, use_graph=False)
+    for i in range(6):
+        l1, l2 = s1(Xd * (1 + 0.01 * i), yd), s2(Xd * (1 + 0.01 * i), yd)
+        assert rel(l1, l2) < 1e-6, (i, float(l1), float(l2))
+    assert s1.opt.t == s2.opt.t == 6
+    if s1.use_graph:
+        assert s1._graph is not None
+    p2 = dict(m2.named_parameters())
+    for n_, p in m1.named_parameters():
+        assert rel(p, p2[n_]) < 1e-6, n_
+
+
 def test_reference_style_training_loop():
     """The drop-in boundary: `train_epoch` with a stock torch optimiser, as src/main.py:212 + src/train.py:466 do."""
     from graphcast_lite_amd.train import get_lat_weights, train_epoch
