@@ -47,7 +47,7 @@ def synthetic_batch(cfg, G, B, seed):
     return X, y
 
 
-def cpu_baseline(cfg, model, grid, budget_s=15.0, max_steps=30):
+def cpu_baseline(cfg, model, grid, budget_s=12.0, max_steps=2000):
     """The CPU oracle executing PyG's op sequence at batch 1: forward +
     weighted MSE + backward + torch Adam, on all host cores of this box."""
     from oracle import model as omodel
@@ -148,6 +148,16 @@ def main():
         dt = float(t.item())
     final_loss = float(loss.item())
 
+    # HBM-side bytes per launch of the same kernel from the rocprofv3 PMC passes (FETCH_SIZE x2
+    # gfx950 correction + WRITE_SIZE; separate --pmc runs, tools/pmc_agg.sh), committed under profiles/
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_agg_mesh.json")) as fh:
+            pmc = json.load(fh)
+        if pmc.get("config") == args.config and pmc.get("batch") == B:
+            traffic = pmc["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     roof = None
     if is_gcn and hip.AGG_PROFILE["events"]:
         ev = hip.AGG_PROFILE["events"]
@@ -157,7 +167,7 @@ def main():
         per_sample = 4 * M * (F + F) + 4 * Ep + 4 * (M + 1) + 4 * M
         achieved = B * per_sample / (ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "agg_kernel (mesh GCNConv aggregate, forward)", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_launch": B * per_sample, "avg_launch_us": ms * 1e3, "launches_timed": len(ev)}
     hip.AGG_PROFILE = None
 

@@ -17,5 +17,5 @@ for d in sorted(glob.glob("$R/gpurun_out/pmc/*/")):
             if "agg_kernel" in r["Kernel_Name"]:
                 acc[(r["Counter_Name"], r["Grid_Size"])].append(float(r["Counter_Value"]))
         for (c, g), v in sorted(acc.items()):
-            print(f"{c:14s} grid={g:>10s} n={len(v):3d} mean={sum(v)/len(v):.4g}")
+            print(f"{c:14s} grid={g:>10s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
 PY
