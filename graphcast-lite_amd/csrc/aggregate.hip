@@ -101,7 +101,10 @@ __global__ __launch_bounds__(256) void agg_kernel(const int32_t* __restrict__ ro
     float nwj = 0.f;
     if (it + 1 < ITER) meta(row + RPW, nstart, nend, ncj, nwj);  // next batch, in flight during this one
 
-    const int deg = end - start;
+    const int deg_all = end - start;
+    const bool heavy = deg_all > gcl::kHeavy;  // done by agg_heavy_kernel (one block per row)
+    const int deg = heavy ? 0 : deg_all;
+    if (heavy) end = start;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     {
       int jj[EW];
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void agg_kernel(const int32_t* __restrict__ ro
         }
       }
     }
-    if (row < n && cactive) {
+    if (row < n && cactive && !heavy) {
       a0 += bz0; a1 += bz1; a2 += bz2; a3 += bz3;
       float* __restrict__ yp = Yb + (int64_t)row * ldy + c0;
       if (VS) {
@@ -170,15 +173,87 @@ __global__ __launch_bounds__(256) void agg_kernel(const int32_t* __restrict__ ro
   }
 }
 
+// One block per (heavy row, sample): the 256/LPR lane groups stride over the row's edges (4 loads
+// in flight each) and are combined through LDS in a fixed order.  Only rows with more than kHeavy
+// edges take this path (polar mesh nodes of E_G2M / E_M2G at 512x256: up to 943 edges), so a
+// single wave no longer serialises hundreds of dependent gathers at the tail of the launch.
+template <int LPR, bool VL, bool VS>
+__global__ __launch_bounds__(256) void agg_heavy_kernel(const int32_t* __restrict__ rows_heavy,
+                                                        const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ col, const float* __restrict__ w,
+                                                        const float* __restrict__ H, int64_t ldh, int64_t bsh,
+                                                        const float* __restrict__ bias, float* __restrict__ Y,
+                                                        int64_t ldy, int64_t bsy, int32_t F) {
+  constexpr int NG = 256 / LPR;
+  __shared__ float red[NG][LPR * 4 + 1];
+  const int row = rows_heavy[blockIdx.x];
+  const int b = blockIdx.y;
+  const int g = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  const int c0 = l * 4;
+  const bool cactive = c0 < F;
+  const int cc = cactive ? c0 : 0;
+  const float* __restrict__ Hb = H + (int64_t)b * bsh;
+  const int start = rowptr[row], end = rowptr[row + 1];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  auto ld4 = [&](int j, float& x0, float& x1, float& x2, float& x3) {
+    const float* p = Hb + (int64_t)j * ldh + cc;
+    if (VL) {
+      const float4 v = *reinterpret_cast<const float4*>(p);
+      x0 = v.x; x1 = v.y; x2 = v.z; x3 = v.w;
+    } else {
+      x0 = p[0];
+      x1 = (cc + 1 < F) ? p[1] : 0.f;
+      x2 = (cc + 2 < F) ? p[2] : 0.f;
+      x3 = (cc + 3 < F) ? p[3] : 0.f;
+    }
+  };
+  for (int e = start + g; e < end; e += 4 * NG) {
+    const int e1 = e + NG, e2 = e + 2 * NG, e3 = e + 3 * NG;
+    const int j0 = col[e], j1 = col[e1 < end ? e1 : e], j2 = col[e2 < end ? e2 : e], j3 = col[e3 < end ? e3 : e];
+    const float w0 = w[e], w1 = e1 < end ? w[e1] : 0.f, w2 = e2 < end ? w[e2] : 0.f, w3 = e3 < end ? w[e3] : 0.f;
+    float p0, p1, p2, p3, q0, q1, q2, q3, r0, r1, r2, r3, s0, s1, s2, s3;
+    ld4(j0, p0, p1, p2, p3);
+    ld4(j1, q0, q1, q2, q3);
+    ld4(j2, r0, r1, r2, r3);
+    ld4(j3, s0, s1, s2, s3);
+    a0 += w0 * p0; a1 += w0 * p1; a2 += w0 * p2; a3 += w0 * p3;
+    if (e1 < end) { a0 += w1 * q0; a1 += w1 * q1; a2 += w1 * q2; a3 += w1 * q3; }
+    if (e2 < end) { a0 += w2 * r0; a1 += w2 * r1; a2 += w2 * r2; a3 += w2 * r3; }
+    if (e3 < end) { a0 += w3 * s0; a1 += w3 * s1; a2 += w3 * s2; a3 += w3 * s3; }
+  }
+  red[g][c0] = a0; red[g][c0 + 1] = a1; red[g][c0 + 2] = a2; red[g][c0 + 3] = a3;
+  __syncthreads();
+  if (g == 0 && cactive) {
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) { t0 += red[q][c0]; t1 += red[q][c0 + 1]; t2 += red[q][c0 + 2]; t3 += red[q][c0 + 3]; }
+    if (bias) {
+      t0 += bias[c0];
+      if (c0 + 1 < F) t1 += bias[c0 + 1];
+      if (c0 + 2 < F) t2 += bias[c0 + 2];
+      if (c0 + 3 < F) t3 += bias[c0 + 3];
+    }
+    float* yp = Y + (int64_t)b * bsy + (int64_t)row * ldy + c0;
+    if (VS) {
+      *reinterpret_cast<float4*>(yp) = make_float4(t0, t1, t2, t3);
+    } else {
+      yp[0] = t0;
+      if (c0 + 1 < F) yp[1] = t1;
+      if (c0 + 2 < F) yp[2] = t2;
+      if (c0 + 3 < F) yp[3] = t3;
+    }
+  }
+}
+
 int agg_env(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
 
 struct AggArgs {
-  const int32_t *rowptr, *col, *ecol;
+  const int32_t *rowptr, *col, *ecol, *heavy;
   const float *w, *ew;
-  int ell_width;
+  int ell_width, n_heavy;
 };
 
 template <int LPR>
@@ -228,6 +303,18 @@ int launch_agg(const AggArgs& ga, const float* h, int64_t ldh, int64_t bsh, cons
 #undef GCL_AGG3
 #undef GCL_AGG4
   GCL_CHECK_LAUNCH();
+  if (ga.n_heavy > 0) {
+    dim3 hgrid((unsigned)ga.n_heavy, (unsigned)B);
+#define GCL_AGGH(VL_, VS_)                                                                                       \
+  hipLaunchKernelGGL((agg_heavy_kernel<LPR, VL_, VS_>), hgrid, block, 0, st, ga.heavy, ga.rowptr, ga.col, ga.w, h, \
+                     ldh, bsh, bias, y, ldy, bsy, F)
+    if (vl && vs) GCL_AGGH(true, true);
+    else if (vl) GCL_AGGH(true, false);
+    else if (vs) GCL_AGGH(false, true);
+    else GCL_AGGH(false, false);
+#undef GCL_AGGH
+    GCL_CHECK_LAUNCH();
+  }
   return GCL_OK;
 }
 
@@ -248,6 +335,9 @@ extern "C" int gcl_aggregate(const gcl_graph_t* g, int32_t transpose, const floa
   ga.ecol = transpose ? g->tecol : g->ecol;
   ga.ew = transpose ? g->tew : g->ew;
   ga.ell_width = transpose ? g->tell_width : g->ell_width;
+  ga.heavy = transpose ? g->theavy : g->heavy;
+  ga.n_heavy = transpose ? g->n_theavy : g->n_heavy;
+  GCL_CHECK_ARG(B <= 65535 || ga.n_heavy == 0, "aggregate: batch too large for the heavy-row launch");
   hipStream_t st = (hipStream_t)stream;
   const int lanes = (F + 3) / 4;
   if (lanes <= 4) return launch_agg<4>(ga, h, ldh, bsh, bias, y, ldy, bsy, g->n, B, F, st);

@@ -44,6 +44,7 @@ constexpr int kWave = 64;     // CDNA wavefront
 constexpr int kNumXCD = 8;    // MI355X: 8 XCDs, blocks are dealt round-robin over them
 constexpr int kNumCU = 256;
 constexpr int kEll = 8;      // stride of the ELL prefix arrays
+constexpr int kHeavy = 64;   // rows with more edges than this get a whole block
 
 __device__ __forceinline__ float prelu_f(float x, float a) { return x > 0.f ? x : a * x; }
 
@@ -67,6 +68,9 @@ struct gcl_graph {
   int32_t *ecol = nullptr, *tecol = nullptr;
   float *ew = nullptr, *tew = nullptr;
   int32_t ell_width = 8, tell_width = 8;  // how many prefix entries the kernels read unconditionally
+  // rows with more than kHeavy edges: skipped by the row-group kernel, done by one block each
+  int32_t *heavy = nullptr, *theavy = nullptr;
+  int32_t n_heavy = 0, n_theavy = 0;
   // host copy of the PyG-order edge list with loops (for export / prune)
   int64_t* h_edges = nullptr;  // [2, e]
 };

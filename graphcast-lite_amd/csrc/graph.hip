@@ -119,20 +119,20 @@ extern "C" int gcl_graph_build_host(const int64_t* ei, int64_t E, int32_t n, int
 template <typename T>
 static int upload(T** dst, const T* src, size_t count) {
   *dst = nullptr;
-  if (count == 0) count = 1;
-  hipError_t e = hipMalloc((void**)dst, count * sizeof(T));
+  const size_t alloc = count ? count : 1;  // empty arrays still get a valid device pointer
+  hipError_t e = hipMalloc((void**)dst, alloc * sizeof(T));
   if (e != hipSuccess) {
-    gcl::set_error("graph_create: hipMalloc(%zu) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    gcl::set_error("graph_create: hipMalloc(%zu) failed: %s", alloc * sizeof(T), hipGetErrorString(e));
     return GCL_ENOMEM;
   }
-  GCL_CHECK_HIP(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+  if (count) GCL_CHECK_HIP(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
   return GCL_OK;
 }
 
 extern "C" void gcl_graph_destroy(gcl_graph_t* g) {
   if (!g) return;
   void* ptrs[] = {g->rowptr, g->col, g->eperm, g->trowptr, g->tcol, g->tslot, g->w, g->tw,
-                  g->ecol, g->tecol, g->ew, g->tew};
+                  g->ecol, g->tecol, g->ew, g->tew, g->heavy, g->theavy};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   free(g->h_edges);
@@ -194,17 +194,29 @@ extern "C" int gcl_graph_create(const int64_t* ei, int64_t E, int32_t n, int32_t
         ewv[(size_t)i * gcl::kEll + k] = in ? ww[rp[i] + k] : 0.f;
       }
     }
-    // smallest power-of-two width that holds >= 80 % of the rows completely (rest: CSR overflow loop)
-    int64_t cum = 0;
+    // width with the least expected work: every row issues `width` unconditional neighbour loads,
+    // rows with more edges pay their remainder plus a fixed penalty for the dependent CSR loop
+    int64_t best_cost = -1;
     int width = gcl::kEll;
-    for (int d = 0; d <= gcl::kEll; ++d) {
-      cum += hist[d];
-      if (cum * 10 >= (int64_t)n * 8) {
-        width = d <= 1 ? 1 : d <= 2 ? 2 : d <= 4 ? 4 : 8;
-        break;
+    for (int cand : {1, 2, 4, 8}) {
+      int64_t cost = (int64_t)n * cand;
+      for (int32_t i = 0; i < n; ++i) {
+        const int32_t d = rp[i + 1] - rp[i];
+        if (d > cand && d <= gcl::kHeavy) cost += (d - cand) + 6;
+      }
+      if (best_cost < 0 || cost < best_cost) {
+        best_cost = cost;
+        width = cand;
       }
     }
+    (void)hist;
     return width;
+  };
+  auto heavy_rows = [&](const std::vector<int32_t>& rp) {
+    std::vector<int32_t> h;
+    for (int32_t i = 0; i < n; ++i)
+      if (rp[i + 1] - rp[i] > gcl::kHeavy) h.push_back(i);
+    return h;
   };
   std::vector<int32_t> ec, tec;
   std::vector<float> ewv, tewv;
@@ -214,6 +226,11 @@ extern "C" int gcl_graph_create(const int64_t* ei, int64_t E, int32_t n, int32_t
   if (!rc) rc = upload(&g->ew, ewv.data(), ewv.size());
   if (!rc) rc = upload(&g->tecol, tec.data(), tec.size());
   if (!rc) rc = upload(&g->tew, tewv.data(), tewv.size());
+  std::vector<int32_t> hv = heavy_rows(rowptr), thv = heavy_rows(trowptr);
+  g->n_heavy = (int32_t)hv.size();
+  g->n_theavy = (int32_t)thv.size();
+  if (!rc) rc = upload(&g->heavy, hv.data(), hv.size());
+  if (!rc) rc = upload(&g->theavy, thv.data(), thv.size());
   if (rc) {
     gcl_graph_destroy(g);
     return rc;

@@ -68,7 +68,10 @@ __device__ __forceinline__ int64_t win_bytes(int64_t nrows, int64_t ld, int F) {
 // ---------------------------------------------------------------------------------------------
 // waves per SIMD the register allocator must leave room for (LDS admits ~3 blocks of 4 waves at
 // K,N <= 64; wide panels are LDS-limited to 1-2 blocks anyway)
-constexpr int lin_min_waves(int NS, int KT) { return (NS <= 2 && KT <= 64) ? 3 : (NS <= 4 && KT <= 128) ? 2 : 1; }
+constexpr int lin_min_waves(int NS, int KT) { return (NS <= 2 && KT <= 64) ? 3 : (NS <= 2 && KT <= 128) ? 2 : 1; }
+// wide panels (NS >= 4) fill the LDS with one block per CU, i.e. one wave per SIMD: give those
+// instantiations the whole register file and fetch Z before the MFMA loop instead of after it
+constexpr bool lin_zpre(int NS, int EPI) { return EPI == 1 && NS >= 4; }
 
 template <int NS, int EPI, int KT, bool VEC>
 __global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel(const float* __restrict__ X, int64_t ldx,
@@ -178,6 +181,20 @@ __global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
 
+    constexpr bool ZPRE = lin_zpre(NS, EPI);
+    float zpre[ZPRE ? NS : 1][16];
+    if (ZPRE) {  // Z of this tile: in flight during the MFMA loop
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int j = s * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = wave * 32 + d_row(r, lane);
+          zpre[ZPRE ? s : 0][r] = buf_ld1(rz, (j < N) ? (unsigned)((rr * ldz + j) * 4) : kOOB);
+        }
+      }
+    }
+
     // k-step pair q covers k = 4q..4q+3: lane half h reads the 8 bytes k = 4q+2h, 4q+2h+1 and
     // feeds .x to the first MFMA (k = 4q | 4q+2) and .y to the second (k = 4q+1 | 4q+3); A and B
     // use the same assignment.  Fragments of pair q+1 are read before the MFMAs of pair q issue.
@@ -214,7 +231,8 @@ __global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rr = wave * 32 + d_row(r, lane);
-          zv[r] = buf_ld1(rz, jok ? (unsigned)((rr * ldz + j) * 4) : kOOB);  // 0 when absent / out of range
+          if (ZPRE) zv[r] = zpre[ZPRE ? s : 0][r];
+          else zv[r] = buf_ld1(rz, jok ? (unsigned)((rr * ldz + j) * 4) : kOOB);  // 0 when absent / out of range
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

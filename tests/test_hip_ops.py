@@ -152,6 +152,38 @@ def test_gcn_aggregate_bipartite_and_padded_ld(hip):
             assert rel(y, ref) < TOL
 
 
+@pytest.mark.parametrize("F,B", [(64, 3), (128, 2), (33, 1)])
+def test_aggregate_heavy_rows(hip, F, B):
+    """Rows with hundreds of in-edges (polar mesh nodes of E_G2M at 512x256 reach 688) take the
+    one-block-per-row path; forward and transpose, GCN and mean weights."""
+    rng = np.random.default_rng(3)
+    n = 2000
+    hubs = np.array([5, 700, 1999])
+    src, dst = [], []
+    for h_, d in zip(hubs, (300, 65, 943)):
+        s_ = rng.choice(n, size=d, replace=False)
+        src.append(s_[s_ != h_]); dst.append(np.full((s_ != h_).sum(), h_))
+    src.append(rng.integers(0, n, 3000)); dst.append(rng.integers(0, n, 3000))
+    ei = torch.from_numpy(np.stack([np.concatenate(src), np.concatenate(dst)]).astype(np.int64))
+    h = rnd(B, n, F, seed=1)
+    for kind, ref_fn in ((hip.GRAPH_GCN, None), (hip.GRAPH_MEAN, None)):
+        G = hip.Graph(ei, n, kind)
+        assert G.max_in_degree > 64
+        if kind == hip.GRAPH_GCN:
+            e2, w = P.gcn_norm(ei, n, torch.float32)
+            ref = P._propagate_sum(h, e2, w, n)
+            hr = h.clone().requires_grad_()
+            P._propagate_sum(hr, e2, w, n).backward(h)
+        else:
+            ref = P.simple_conv_mean(h, ei)
+            hr = h.clone().requires_grad_()
+            P.simple_conv_mean(hr, ei).backward(h)
+        y = hip.aggregate(G, h.to(DEV), None)
+        assert rel(y, ref) < TOL
+        dh = hip.aggregate(G, h.to(DEV), None, transpose=True)
+        assert rel(dh, hr.grad) < TOL
+
+
 def test_mean_aggregate(hip):
     g = build_graphs(experiment("baseline", mesh_levels=[1, 2]))
     n = g["G"] + g["M"]
