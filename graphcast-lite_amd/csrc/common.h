@@ -65,7 +65,7 @@ struct gcl_graph {
   int32_t *trowptr = nullptr, *tcol = nullptr, *tslot = nullptr;
   float *w = nullptr, *tw = nullptr;
   // fixed-stride prefix of every row (first kEll edges in CSR order; padding: col = row, w = 0)
-  int32_t *ecol = nullptr, *tecol = nullptr;
+  int32_t *ecol = nullptr, *tecol = nullptr, *teslot = nullptr;  // teslot: forward slot of a transposed prefix edge
   float *ew = nullptr, *tew = nullptr;
   int32_t ell_width = 8, tell_width = 8;  // how many prefix entries the kernels read unconditionally
   // rows with more than kHeavy edges: skipped by the row-group kernel, done by one block each

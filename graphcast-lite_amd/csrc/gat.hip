@@ -64,13 +64,15 @@ __global__ __launch_bounds__(256) void gat_scores_kernel(const float* __restrict
 
 template <int LPR>
 __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict__ rowptr,
-                                                      const int32_t* __restrict__ col, const float* __restrict__ Hf,
+                                                      const int32_t* __restrict__ col,
+                                                      const int32_t* __restrict__ ecol, const float* __restrict__ Hf,
                                                       int64_t ldh, int64_t bsh, const float* __restrict__ a_s,
                                                       const float* __restrict__ a_d, const float* __restrict__ bias,
                                                       float* __restrict__ alpha, float* __restrict__ Y, int64_t ldy,
                                                       int64_t bsy, int32_t n, int64_t Ep, int32_t B, int32_t H,
                                                       int32_t C, int32_t nRB, int32_t xcd_map) {
   constexpr int RPW = 64 / LPR, RPB = RPW * 4;
+  constexpr int EL = LPR < gcl::kEll ? LPR : gcl::kEll;
   const int bid = blockIdx.x;
   int b, rb;
   if (xcd_map) {
@@ -84,32 +86,72 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict_
   if (b >= B) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  const int gbase = sub * LPR;
   const int row = rb * RPB + wave * RPW + sub;
   const int HC = H * C, lph = C >> 2;
-  const bool active = (row < n) && (c0 < HC);
-  const int h = active ? c0 / C : 0;
+  const bool cact = c0 < HC;
+  const bool active = (row < n) && cact;
+  const int cc = cact ? c0 : 0;
+  const int h = cc / C;
+  const int rc = row < n ? row : n - 1;
   const float* __restrict__ Hb = Hf + (int64_t)b * bsh;
   const float* __restrict__ as_b = a_s + (int64_t)b * n * H;
-  int start = 0, end = 0;
-  float ad = 0.f;
-  if (active) {
-    start = rowptr[row];
-    end = rowptr[row + 1];
-    ad = a_d[((int64_t)b * n + row) * H + h];
-  }
-  float m = -INFINITY;
-  for (int e = start; e < end; ++e) m = fmaxf(m, leaky(as_b[(int64_t)col[e] * H + h] + ad));
-  float den = 0.f;
-  for (int e = start; e < end; ++e) den += expf(leaky(as_b[(int64_t)col[e] * H + h] + ad) - m);
-  const float inv = 1.f / (den + 1e-16f);
-  float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  // metadata: one round trip (the ELL prefix does not depend on rowptr)
+  const int start = rowptr[rc], end = rowptr[rc + 1];
+  const int cj = ecol[(int64_t)rc * gcl::kEll + (l & (EL - 1))];
+  const float ad = a_d[((int64_t)b * n + rc) * H + h];
+  const int deg = end - start;
   const bool leader = active && (l % lph) == 0;
-  for (int e = start; e < end; ++e) {
-    const int j = col[e];
-    const float al = expf(leaky(as_b[(int64_t)j * H + h] + ad) - m) * inv;
-    const float4 v = *reinterpret_cast<const float4*>(Hb + (int64_t)j * ldh + c0);
-    a0 += al * v.x; a1 += al * v.y; a2 += al * v.z; a3 += al * v.w;
-    if (leader && alpha) alpha[((int64_t)b * Ep + e) * H + h] = al;
+  float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+
+  if (!__any(deg > EL)) {
+    // fast path: <= EL in-edges -> indices, scores and neighbour rows are all in flight together;
+    // the softmax of this lane's head lives in registers (no cross-lane traffic)
+    int jj[EL];
+    float sc[EL];
+#pragma unroll
+    for (int k = 0; k < EL; ++k) jj[k] = __shfl(cj, gbase + k, 64);
+#pragma unroll
+    for (int k = 0; k < EL; ++k) sc[k] = as_b[(int64_t)jj[k] * H + h];
+    float4 v[EL];
+#pragma unroll
+    for (int k = 0; k < EL; ++k) v[k] = *reinterpret_cast<const float4*>(Hb + (int64_t)jj[k] * ldh + cc);
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < EL; ++k) {
+      sc[k] = leaky(sc[k] + ad);
+      m = (k < deg) ? fmaxf(m, sc[k]) : m;
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < EL; ++k) {
+      sc[k] = (k < deg) ? expf(sc[k] - m) : 0.f;
+      den += sc[k];
+    }
+    const float inv = 1.f / (den + 1e-16f);
+#pragma unroll
+    for (int k = 0; k < EL; ++k) {
+      const float al = sc[k] * inv;
+      const bool in = k < deg;
+      a0 += in ? al * v[k].x : 0.f;
+      a1 += in ? al * v[k].y : 0.f;
+      a2 += in ? al * v[k].z : 0.f;
+      a3 += in ? al * v[k].w : 0.f;
+      if (leader && alpha && in) alpha[((int64_t)b * Ep + start + k) * H + h] = al;
+    }
+  } else {
+    float m = -INFINITY;
+    for (int e = start; e < end; ++e) m = fmaxf(m, leaky(as_b[(int64_t)col[e] * H + h] + ad));
+    float den = 0.f;
+    for (int e = start; e < end; ++e) den += expf(leaky(as_b[(int64_t)col[e] * H + h] + ad) - m);
+    const float inv = 1.f / (den + 1e-16f);
+    for (int e = start; e < end; ++e) {
+      const int j = col[e];
+      const float al = expf(leaky(as_b[(int64_t)j * H + h] + ad) - m) * inv;
+      const float4 v = *reinterpret_cast<const float4*>(Hb + (int64_t)j * ldh + cc);
+      a0 += al * v.x; a1 += al * v.y; a2 += al * v.z; a3 += al * v.w;
+      if (leader && alpha) alpha[((int64_t)b * Ep + e) * H + h] = al;
+    }
   }
   // mean over heads: lanes holding the same channel of different heads are lph apart
   for (int off = lph; off < lph * H; off <<= 1) {
@@ -135,6 +177,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict_
 template <int LPR>
 __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const int32_t* __restrict__ rowptr,
                                                           const int32_t* __restrict__ col,
+                                                          const int32_t* __restrict__ ecol,
                                                           const float* __restrict__ dY, int64_t lddy, int64_t bsdy,
                                                           const float* __restrict__ Hf, int64_t ldh, int64_t bsh,
                                                           const float* __restrict__ a_s, const float* __restrict__ a_d,
@@ -142,45 +185,81 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const int32_t* __restr
                                                           float* __restrict__ dad, int32_t n, int64_t Ep, int32_t B,
                                                           int32_t H, int32_t C, int32_t nRB) {
   constexpr int RPW = 64 / LPR, RPB = RPW * 4;
+  constexpr int EL = LPR < gcl::kEll ? LPR : gcl::kEll;
   const int b = blockIdx.x / nRB, rb = blockIdx.x % nRB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  const int gbase = sub * LPR;
   const int row = rb * RPB + wave * RPW + sub;
   const int HC = H * C, lph = C >> 2;
-  const bool active = (row < n) && (c0 < HC);
-  const int h = active ? c0 / C : 0;
-  const int cc = c0 - h * C;  // channel inside the head = channel of dy
+  const bool cact = c0 < HC;
+  const bool active = (row < n) && cact;
+  const int cc0 = cact ? c0 : 0;
+  const int h = cc0 / C;
+  const int cc = cc0 - h * C;  // channel inside the head = channel of dy
+  const int rc = row < n ? row : n - 1;
   const float* __restrict__ Hb = Hf + (int64_t)b * bsh;
-  int start = 0, end = 0;
-  float g0 = 0, g1 = 0, g2 = 0, g3 = 0, ad = 0.f;
-  if (active) {
-    start = rowptr[row];
-    end = rowptr[row + 1];
-    const float* dp = dY + (int64_t)b * bsdy + (int64_t)row * lddy + cc;
-    const float s = 1.f / (float)H;
-    g0 = dp[0] * s; g1 = dp[1] * s; g2 = dp[2] * s; g3 = dp[3] * s;
-    ad = a_d[((int64_t)b * n + row) * H + h];
-  }
-  // the trip count must be uniform across the lanes that shuffle together (one row group): it is
-  float t = 0.f;
-  for (int e = start; e < end; ++e) {
-    const float4 v = *reinterpret_cast<const float4*>(Hb + (int64_t)col[e] * ldh + c0);
-    float d = g0 * v.x + g1 * v.y + g2 * v.z + g3 * v.w;
-    for (int off = lph >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
-    t += alpha[((int64_t)b * Ep + e) * H + h] * d;
-  }
-  float sum_de = 0.f;
+  const float* __restrict__ as_b = a_s + (int64_t)b * n * H;
+  const int start = rowptr[rc], end = rowptr[rc + 1];
+  const int cj = ecol[(int64_t)rc * gcl::kEll + (l & (EL - 1))];
+  const float ad = a_d[((int64_t)b * n + rc) * H + h];
+  const float* dp = dY + (int64_t)b * bsdy + (int64_t)rc * lddy + cc;
+  const float sH = 1.f / (float)H;
+  const float g0 = cact ? dp[0] * sH : 0.f, g1 = cact ? dp[1] * sH : 0.f;
+  const float g2 = cact ? dp[2] * sH : 0.f, g3 = cact ? dp[3] * sH : 0.f;
+  const int deg = end - start;
   const bool leader = active && (l % lph) == 0;
-  for (int e = start; e < end; ++e) {
-    const int j = col[e];
-    const float4 v = *reinterpret_cast<const float4*>(Hb + (int64_t)j * ldh + c0);
-    float d = g0 * v.x + g1 * v.y + g2 * v.z + g3 * v.w;
-    for (int off = lph >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
-    const float al = alpha[((int64_t)b * Ep + e) * H + h];
-    const float pre = a_s[((int64_t)b * n + j) * H + h] + ad;
-    const float dev = al * (d - t) * (pre > 0.f ? 1.f : kNegSlope);
-    sum_de += dev;
-    if (leader) de[((int64_t)b * Ep + e) * H + h] = dev;
+  float sum_de = 0.f;
+
+  if (!__any(deg > EL)) {
+    int jj[EL];
+    float4 v[EL];
+    float al[EL], pre[EL], d[EL];
+#pragma unroll
+    for (int k = 0; k < EL; ++k) jj[k] = __shfl(cj, gbase + k, 64);
+#pragma unroll
+    for (int k = 0; k < EL; ++k) v[k] = *reinterpret_cast<const float4*>(Hb + (int64_t)jj[k] * ldh + cc0);
+#pragma unroll
+    for (int k = 0; k < EL; ++k) {
+      const int e = (k < deg) ? start + k : start;
+      al[k] = alpha[((int64_t)b * Ep + e) * H + h];
+      pre[k] = as_b[(int64_t)jj[k] * H + h] + ad;
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < EL; ++k) {
+      float dk = g0 * v[k].x + g1 * v[k].y + g2 * v[k].z + g3 * v[k].w;
+      for (int off = lph >> 1; off > 0; off >>= 1) dk += __shfl_xor(dk, off, 64);
+      d[k] = dk;
+      al[k] = (k < deg) ? al[k] : 0.f;
+      t += al[k] * dk;
+    }
+#pragma unroll
+    for (int k = 0; k < EL; ++k) {
+      const float dev = al[k] * (d[k] - t) * (pre[k] > 0.f ? 1.f : kNegSlope);
+      sum_de += (k < deg) ? dev : 0.f;
+      if (leader && k < deg) de[((int64_t)b * Ep + start + k) * H + h] = dev;
+    }
+  } else {
+    // generic path: the trip count is uniform across the lanes that shuffle together (one row group)
+    float t = 0.f;
+    for (int e = start; e < end; ++e) {
+      const float4 v = *reinterpret_cast<const float4*>(Hb + (int64_t)col[e] * ldh + cc0);
+      float d = g0 * v.x + g1 * v.y + g2 * v.z + g3 * v.w;
+      for (int off = lph >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+      t += alpha[((int64_t)b * Ep + e) * H + h] * d;
+    }
+    for (int e = start; e < end; ++e) {
+      const int j = col[e];
+      const float4 v = *reinterpret_cast<const float4*>(Hb + (int64_t)j * ldh + cc0);
+      float d = g0 * v.x + g1 * v.y + g2 * v.z + g3 * v.w;
+      for (int off = lph >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+      const float a_ = alpha[((int64_t)b * Ep + e) * H + h];
+      const float pr = as_b[(int64_t)j * H + h] + ad;
+      const float dev = a_ * (d - t) * (pr > 0.f ? 1.f : kNegSlope);
+      sum_de += dev;
+      if (leader) de[((int64_t)b * Ep + e) * H + h] = dev;
+    }
   }
   if (leader) dad[((int64_t)b * n + row) * H + h] = sum_de;
 }
@@ -192,39 +271,89 @@ template <int LPR>
 __global__ __launch_bounds__(256) void gat_bwd_src_kernel(const int32_t* __restrict__ trowptr,
                                                           const int32_t* __restrict__ tcol,
                                                           const int32_t* __restrict__ tslot,
+                                                          const int32_t* __restrict__ tecol,
+                                                          const int32_t* __restrict__ teslot,
                                                           const float* __restrict__ dY, int64_t lddy, int64_t bsdy,
                                                           const float* __restrict__ alpha, const float* __restrict__ de,
                                                           const float* __restrict__ dad, const float* __restrict__ att_s,
                                                           const float* __restrict__ att_d, float* __restrict__ das,
                                                           float* __restrict__ dH, int64_t lddh, int64_t bsdh,
                                                           int32_t n, int64_t Ep, int32_t B, int32_t H, int32_t C,
-                                                          int32_t nRB) {
+                                                          int32_t nRB, int32_t vdy) {
   constexpr int RPW = 64 / LPR, RPB = RPW * 4;
+  constexpr int EL = LPR < gcl::kEll ? LPR : gcl::kEll;
   const int b = blockIdx.x / nRB, rb = blockIdx.x % nRB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  const int gbase = sub * LPR;
   const int row = rb * RPB + wave * RPW + sub;
   const int HC = H * C, lph = C >> 2;
-  if (!(row < n) || !(c0 < HC)) return;
-  const int h = c0 / C, cc = c0 - h * C;
+  const bool cact = c0 < HC;
+  const bool active = (row < n) && cact;
+  const int cc0 = cact ? c0 : 0;
+  const int h = cc0 / C, cc = cc0 - h * C;
+  const int rc = row < n ? row : n - 1;
   const float s = 1.f / (float)H;
-  const int start = trowptr[row], end = trowptr[row + 1];
+  const int start = trowptr[rc], end = trowptr[rc + 1];
+  const int ci = tecol[(int64_t)rc * gcl::kEll + (l & (EL - 1))];
+  const int si = teslot[(int64_t)rc * gcl::kEll + (l & (EL - 1))];
+  const int deg = end - start;
+  const float* dYb = dY + (int64_t)b * bsdy;
   float a0 = 0, a1 = 0, a2 = 0, a3 = 0, sde = 0.f;
-  for (int e = start; e < end; ++e) {
-    const int i = tcol[e];
-    const int64_t sl = ((int64_t)b * Ep + tslot[e]) * H + h;
-    const float al = alpha[sl] * s;
-    sde += de[sl];
-    const float* dp = dY + (int64_t)b * bsdy + (int64_t)i * lddy + cc;
-    a0 += al * dp[0]; a1 += al * dp[1]; a2 += al * dp[2]; a3 += al * dp[3];
+  auto ld_dy = [&](int i) -> float4 {
+    const float* p = dYb + (int64_t)i * lddy + cc;
+    if (vdy) return *reinterpret_cast<const float4*>(p);
+    return make_float4(p[0], p[1], p[2], p[3]);
+  };
+  if (!__any(deg > EL)) {
+    int ii[EL], ss[EL];
+#pragma unroll
+    for (int k = 0; k < EL; ++k) {
+      ii[k] = __shfl(ci, gbase + k, 64);
+      ss[k] = __shfl(si, gbase + k, 64);
+    }
+    float4 v[EL];
+    float al[EL], dk[EL];
+#pragma unroll
+    for (int k = 0; k < EL; ++k) v[k] = ld_dy(ii[k]);
+#pragma unroll
+    for (int k = 0; k < EL; ++k) {
+      const int64_t sl = ((int64_t)b * Ep + ss[k]) * H + h;
+      al[k] = alpha[sl];
+      dk[k] = de[sl];
+    }
+#pragma unroll
+    for (int k = 0; k < EL; ++k) {
+      const bool in = k < deg;
+      const float a_ = al[k] * s;
+      sde += in ? dk[k] : 0.f;
+      a0 += in ? a_ * v[k].x : 0.f;
+      a1 += in ? a_ * v[k].y : 0.f;
+      a2 += in ? a_ * v[k].z : 0.f;
+      a3 += in ? a_ * v[k].w : 0.f;
+    }
+  } else {
+    for (int e = start; e < end; ++e) {
+      const int i = tcol[e];
+      const int64_t sl = ((int64_t)b * Ep + tslot[e]) * H + h;
+      const float a_ = alpha[sl] * s;
+      sde += de[sl];
+      const float4 v = ld_dy(i);
+      a0 += a_ * v.x; a1 += a_ * v.y; a2 += a_ * v.z; a3 += a_ * v.w;
+    }
   }
+  if (!active) return;
   const float dd = dad[((int64_t)b * n + row) * H + h];
   a0 += sde * att_s[c0] + dd * att_d[c0];
   a1 += sde * att_s[c0 + 1] + dd * att_d[c0 + 1];
   a2 += sde * att_s[c0 + 2] + dd * att_d[c0 + 2];
   a3 += sde * att_s[c0 + 3] + dd * att_d[c0 + 3];
   float* o = dH + (int64_t)b * bsdh + (int64_t)row * lddh + c0;
-  o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+  if ((lddh & 3) == 0 && (bsdh & 3) == 0 && ((uintptr_t)dH & 15) == 0) {
+    *reinterpret_cast<float4*>(o) = make_float4(a0, a1, a2, a3);
+  } else {
+    o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+  }
   if ((l % lph) == 0) das[((int64_t)b * n + row) * H + h] = sde;
 }
 
@@ -335,8 +464,8 @@ extern "C" int gcl_gat_fwd(const gcl_graph_t* g, const float* h, int64_t ldh, in
   const int xcd_map = B >= 8 ? 1 : 0;
   const int64_t nb = xcd_map ? (int64_t)8 * gcl::cdiv(B, 8) * nRB : (int64_t)B * nRB;
 #define CALL(L)                                                                                                       \
-  hipLaunchKernelGGL((gat_fwd_kernel<L>), dim3((unsigned)nb), dim3(256), 0, st, g->rowptr, g->col, h, ldh, bsh, a_src, \
-                     a_dst, bias, alpha, y, ldy, bsy, g->n, g->e, B, H, C, nRB, xcd_map)
+  hipLaunchKernelGGL((gat_fwd_kernel<L>), dim3((unsigned)nb), dim3(256), 0, st, g->rowptr, g->col, g->ecol, h, ldh, \
+                     bsh, a_src, a_dst, bias, alpha, y, ldy, bsy, g->n, g->e, B, H, C, nRB, xcd_map)
   GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
   GCL_CHECK_LAUNCH();
@@ -377,15 +506,17 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
   const int rpb = (64 / lpr) * 4;
   const int32_t nRB = (int32_t)gcl::cdiv(g->n, rpb);
   const unsigned nb = (unsigned)((int64_t)B * nRB);
+  const int vdy = (lddy % 4 == 0) && (bsdy % 4 == 0) && (C % 4 == 0) && gcl::aligned16(dy);
 #define CALL(L)                                                                                                    \
-  hipLaunchKernelGGL((gat_bwd_dst_kernel<L>), dim3(nb), dim3(256), 0, st, g->rowptr, g->col, dy, lddy, bsdy, h, ldh, \
-                     bsh, a_src, a_dst, alpha, de, dad, g->n, g->e, B, H, C, nRB)
+  hipLaunchKernelGGL((gat_bwd_dst_kernel<L>), dim3(nb), dim3(256), 0, st, g->rowptr, g->col, g->ecol, dy, lddy,     \
+                     bsdy, h, ldh, bsh, a_src, a_dst, alpha, de, dad, g->n, g->e, B, H, C, nRB)
   GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
   GCL_CHECK_LAUNCH();
 #define CALL(L)                                                                                                       \
-  hipLaunchKernelGGL((gat_bwd_src_kernel<L>), dim3(nb), dim3(256), 0, st, g->trowptr, g->tcol, g->tslot, dy, lddy,    \
-                     bsdy, alpha, de, dad, att_src, att_dst, das, dh, lddh, bsdh, g->n, g->e, B, H, C, nRB)
+  hipLaunchKernelGGL((gat_bwd_src_kernel<L>), dim3(nb), dim3(256), 0, st, g->trowptr, g->tcol, g->tslot, g->tecol,    \
+                     g->teslot, dy, lddy, bsdy, alpha, de, dad, att_src, att_dst, das, dh, lddh, bsdh, g->n, g->e, B, \
+                     H, C, nRB, vdy)
   GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
   GCL_CHECK_LAUNCH();

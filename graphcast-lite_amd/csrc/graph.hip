@@ -132,7 +132,7 @@ static int upload(T** dst, const T* src, size_t count) {
 extern "C" void gcl_graph_destroy(gcl_graph_t* g) {
   if (!g) return;
   void* ptrs[] = {g->rowptr, g->col, g->eperm, g->trowptr, g->tcol, g->tslot, g->w, g->tw,
-                  g->ecol, g->tecol, g->ew, g->tew, g->heavy, g->theavy};
+                  g->ecol, g->tecol, g->ew, g->tew, g->heavy, g->theavy, g->teslot};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   free(g->h_edges);
@@ -226,6 +226,11 @@ extern "C" int gcl_graph_create(const int64_t* ei, int64_t E, int32_t n, int32_t
   if (!rc) rc = upload(&g->ew, ewv.data(), ewv.size());
   if (!rc) rc = upload(&g->tecol, tec.data(), tec.size());
   if (!rc) rc = upload(&g->tew, tewv.data(), tewv.size());
+  std::vector<int32_t> tes((size_t)n * gcl::kEll, 0);
+  for (int32_t i = 0; i < n; ++i)
+    for (int k = 0; k < gcl::kEll && trowptr[i] + k < trowptr[i + 1]; ++k)
+      tes[(size_t)i * gcl::kEll + k] = tslot[trowptr[i] + k];
+  if (!rc) rc = upload(&g->teslot, tes.data(), tes.size());
   std::vector<int32_t> hv = heavy_rows(rowptr), thv = heavy_rows(trowptr);
   g->n_heavy = (int32_t)hv.size();
   g->n_theavy = (int32_t)thv.size();
