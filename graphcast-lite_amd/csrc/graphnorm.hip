@@ -1,19 +1,190 @@
-// PyG LayerNorm(mode="graph") - statistics over all n*F elements of a sample.
-// No BASELINE.json configuration uses graph mode (every config sets layer_norm_mode="node"), so the
-// entry points are declared and report GCL_EUNSUPPORTED until the row in SURVEY.md §8f is reached.
+// PyG LayerNorm(mode="graph") forward + backward (reference construction
+// src/models.py:102-104,368-374): statistics over ALL n*F elements of one sample's tensor,
+//   y = (x - mean) / (std_biased + eps) * gamma + beta        (eps added to the std, not inside sqrt)
+// per sample under batching.  Two launches per direction: per-(sample, chunk) partial sums in
+// fp64 (the variance is formed as E[x^2] - mean^2, so the sums must not lose bits), then an apply
+// pass that re-derives the per-sample scalars from the partials in a fixed order.
+//   stats[b] = (mean, 1/(std + eps))
+// backward, with g = dy*gamma, d = std + eps, N = n*F:
+//   dx = (g - mean(g)) / d - (x - mean) * sum(g (x - mean)) / (N std d^2)
+//   dgamma[c] = sum dy * xhat,  dbeta[c] = sum dy
+#include <algorithm>
+
 #include "common.h"
 
-extern "C" size_t gcl_graphnorm_ws_bytes(int32_t, int32_t, int32_t) { return 0; }
+namespace {
 
-extern "C" int gcl_graphnorm_fwd(const float*, int64_t, int64_t, const float*, const float*, float, float*, int64_t,
-                                 int64_t, float*, int32_t, int32_t, int32_t, void*, size_t, gcl_stream_t) {
-  gcl::set_error("graphnorm_fwd: LayerNorm(mode=\"graph\") is not implemented on the HIP path yet");
-  return GCL_EUNSUPPORTED;
+constexpr int kGnChunks = 64;  // partial sums per sample
+
+// part[b][chunk][2] = (sum a, sum b) over the chunk's rows, with
+//   MODE 0: a = x, b = x^2          MODE 1: a = dy*gamma, b = dy*gamma*(x - mean)
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ X, int64_t ldx, int64_t bsx,
+                                                         const float* __restrict__ dY, int64_t lddy, int64_t bsdy,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ stats, double* __restrict__ part,
+                                                         int32_t n, int32_t F) {
+  __shared__ double red[2][4];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int rows_per = (n + kGnChunks - 1) / kGnChunks;
+  const int r0 = chunk * rows_per, r1 = min(n, r0 + rows_per);
+  const float mean = (MODE == 1) ? stats[2 * b] : 0.f;
+  double sa = 0.0, sb = 0.0;
+  const int64_t total = (int64_t)(r1 > r0 ? r1 - r0 : 0) * F;
+  for (int64_t idx = threadIdx.x; idx < total; idx += 256) {
+    const int r = r0 + (int)(idx / F), c = (int)(idx % F);
+    const float x = X[(int64_t)b * bsx + (int64_t)r * ldx + c];
+    if (MODE == 0) {
+      sa += (double)x;
+      sb += (double)x * (double)x;
+    } else {
+      const float g = dY[(int64_t)b * bsdy + (int64_t)r * lddy + c] * gamma[c];
+      sa += (double)g;
+      sb += (double)g * (double)(x - mean);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    sa += __shfl_down(sa, off, 64);
+    sb += __shfl_down(sb, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = sa;
+    red[1][threadIdx.x >> 6] = sb;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* p = part + ((int64_t)b * kGnChunks + chunk) * 2;
+    p[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    p[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
 }
 
-extern "C" int gcl_graphnorm_bwd(const float*, int64_t, int64_t, const float*, int64_t, int64_t, const float*,
-                                 const float*, float, float*, int64_t, int64_t, float*, float*, int32_t, int32_t,
-                                 int32_t, int32_t, void*, size_t, gcl_stream_t) {
-  gcl::set_error("graphnorm_bwd: LayerNorm(mode=\"graph\") is not implemented on the HIP path yet");
-  return GCL_EUNSUPPORTED;
+__device__ __forceinline__ void gn_sum_parts(const double* part, int b, double& s0, double& s1) {
+  s0 = 0.0;
+  s1 = 0.0;
+  for (int k = 0; k < kGnChunks; ++k) {  // fixed order: deterministic
+    s0 += part[((int64_t)b * kGnChunks + k) * 2];
+    s1 += part[((int64_t)b * kGnChunks + k) * 2 + 1];
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_fwd_apply_kernel(const float* __restrict__ X, int64_t ldx, int64_t bsx,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps,
+                                                           const double* __restrict__ part, float* __restrict__ Y,
+                                                           int64_t ldy, int64_t bsy, float* __restrict__ stats,
+                                                           int32_t n, int32_t F) {
+  const int b = blockIdx.y;
+  double s0, s1;
+  gn_sum_parts(part, b, s0, s1);
+  const double N = (double)n * (double)F;
+  const double mean_d = s0 / N;
+  double var = s1 / N - mean_d * mean_d;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)mean_d;
+  const float rinv = (float)(1.0 / (sqrt(var) + (double)eps));
+  if (blockIdx.x == 0 && threadIdx.x == 0 && stats) {
+    stats[2 * b] = mean;
+    stats[2 * b + 1] = rinv;
+  }
+  const int64_t total = (int64_t)n * F;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int r = (int)(idx / F), c = (int)(idx % F);
+    const float x = X[(int64_t)b * bsx + (int64_t)r * ldx + c];
+    Y[(int64_t)b * bsy + (int64_t)r * ldy + c] = (x - mean) * rinv * gamma[c] + beta[c];
+  }
+}
+
+// dx and per-block column partials of (dy*xhat | dy): cpart[block][2][F]
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ dY, int64_t lddy, int64_t bsdy,
+                                                           const float* __restrict__ X, int64_t ldx, int64_t bsx,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ stats, float eps,
+                                                           const double* __restrict__ part, float* __restrict__ dX,
+                                                           int64_t lddx, int64_t bsdx, float* __restrict__ cpart,
+                                                           int32_t n, int32_t F, int32_t rows_per_block) {
+  extern __shared__ float cs[];  // [256 / F][2][F]: one slot per thread, summed in a fixed order
+  const int b = blockIdx.y;
+  double s0, s1;
+  gn_sum_parts(part, b, s0, s1);
+  const double N = (double)n * (double)F;
+  const float mean = stats[2 * b], rinv = stats[2 * b + 1];
+  const double d = 1.0 / (double)rinv;       // std + eps
+  const double sd = d - (double)eps;         // std
+  const float gmean = (float)(s0 / N);
+  const float k2 = sd > 0.0 ? (float)(s1 / (N * sd * d * d)) : 0.f;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+  // thread t owns column t % F of rows r0 + t / F, stepping 256 / F rows (F <= 256): its column is fixed
+  const int c = threadIdx.x % F, rsub = threadIdx.x / F, rstep = 256 / F;
+  float pg = 0.f, pb = 0.f;
+  if (rsub < rstep)
+    for (int r = r0 + rsub; r < r1; r += rstep) {
+      const float x = X[(int64_t)b * bsx + (int64_t)r * ldx + c];
+      const float dy = dY[(int64_t)b * bsdy + (int64_t)r * lddy + c];
+      const float xc = x - mean;
+      const float g = dy * gamma[c];
+      dX[(int64_t)b * bsdx + (int64_t)r * lddx + c] = (g - gmean) * rinv - xc * k2;
+      pg += dy * xc * rinv;
+      pb += dy;
+    }
+  if (rsub < rstep) {
+    cs[rsub * 2 * F + c] = pg;
+    cs[rsub * 2 * F + F + c] = pb;
+  }
+  __syncthreads();
+  float* out = cpart + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * F;
+  for (int q = threadIdx.x; q < 2 * F; q += 256) {
+    float t = 0.f;
+    for (int k = 0; k < rstep; ++k) t += cs[k * 2 * F + q];
+    out[q] = t;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t gcl_graphnorm_ws_bytes(int32_t B, int32_t n, int32_t F) {
+  const size_t parts = (size_t)B * kGnChunks * 2 * sizeof(double);
+  const size_t nblk = (size_t)gcl::cdiv(n, 256);
+  const size_t cparts = (size_t)B * nblk * 2 * (size_t)F * sizeof(float);
+  return parts + cparts + 64;
+}
+
+extern "C" int gcl_graphnorm_fwd(const float* x, int64_t ldx, int64_t bsx, const float* gamma, const float* beta,
+                                 float eps, float* y, int64_t ldy, int64_t bsy, float* stats, int32_t B, int32_t n,
+                                 int32_t F, void* ws, size_t ws_bytes, gcl_stream_t stream) {
+  GCL_CHECK_ARG(x && gamma && beta && y, "graphnorm_fwd: null argument");
+  GCL_CHECK_ARG(B > 0 && n > 0 && F > 0 && ldx >= F && ldy >= F, "graphnorm_fwd: bad shape");
+  GCL_CHECK_ARG(ws && ws_bytes >= gcl_graphnorm_ws_bytes(B, n, F) && gcl::aligned16(ws), "graphnorm_fwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  double* part = (double*)ws;
+  hipLaunchKernelGGL((gn_partial_kernel<0>), dim3(kGnChunks, B), dim3(256), 0, st, x, ldx, bsx, nullptr, 0, 0, nullptr,
+                     nullptr, part, n, F);
+  const unsigned nb = (unsigned)std::min<int64_t>(gcl::cdiv((int64_t)n * F, 256), 1024);
+  hipLaunchKernelGGL(gn_fwd_apply_kernel, dim3(nb, B), dim3(256), 0, st, x, ldx, bsx, gamma, beta, eps, part, y, ldy,
+                     bsy, stats, n, F);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+extern "C" int gcl_graphnorm_bwd(const float* dy, int64_t lddy, int64_t bsdy, const float* x, int64_t ldx,
+                                 int64_t bsx, const float* gamma, const float* stats, float eps, float* dx,
+                                 int64_t lddx, int64_t bsdx, float* dgamma, float* dbeta, int32_t accumulate,
+                                 int32_t B, int32_t n, int32_t F, void* ws, size_t ws_bytes, gcl_stream_t stream) {
+  GCL_CHECK_ARG(dy && x && gamma && stats && dx && dgamma && dbeta, "graphnorm_bwd: null argument");
+  GCL_CHECK_ARG(B > 0 && n > 0 && F > 0 && F <= 256 && ldx >= F && lddy >= F && lddx >= F, "graphnorm_bwd: bad shape (F <= 256)");
+  GCL_CHECK_ARG(ws && ws_bytes >= gcl_graphnorm_ws_bytes(B, n, F) && gcl::aligned16(ws), "graphnorm_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  double* part = (double*)ws;
+  float* cpart = (float*)(part + (size_t)B * kGnChunks * 2);
+  hipLaunchKernelGGL((gn_partial_kernel<1>), dim3(kGnChunks, B), dim3(256), 0, st, x, ldx, bsx, dy, lddy, bsdy, gamma,
+                     stats, part, n, F);
+  const int rows_per_block = 256;
+  const unsigned nblk = (unsigned)gcl::cdiv(n, rows_per_block);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nblk, B), dim3(256), 2 * (size_t)F * (256 / F) * sizeof(float), st, dy, lddy, bsdy, x,
+                     ldx, bsx, gamma, stats, eps, part, dx, lddx, bsdx, cpart, n, F, rows_per_block);
+  GCL_CHECK_LAUNCH();
+  const int nparts = (int)(nblk * B);
+  int rc = gcl::launch_reduce_parts(cpart, nparts, 2 * F, 2 * F, dgamma, F, 1, F, accumulate, st);
+  if (rc) return rc;
+  return gcl::launch_reduce_parts(cpart + F, nparts, 2 * F, 2 * F, dbeta, F, 1, F, accumulate, st);
 }

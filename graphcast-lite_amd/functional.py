@@ -262,6 +262,27 @@ class LayerNormFn(torch.autograd.Function):
         return (dx.view(dy.shape), None, None) + G.out()
 
 
+class GraphNormFn(torch.autograd.Function):
+    """PyG LayerNorm(mode="graph"): statistics over all n*F elements of each sample."""
+
+    @staticmethod
+    def forward(ctx, x, owner, eps, gamma, beta):
+        squeeze = x.dim() == 2
+        x3 = _flat3(x.detach())
+        y, stats = hip.graphnorm_fwd(x3, gamma.detach(), beta.detach(), eps)
+        ctx.x3, ctx.stats, ctx.params, ctx.eps, ctx.squeeze = x3, stats, (gamma, beta), eps, squeeze
+        return y[0] if squeeze else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        gamma, beta = ctx.params
+        G = _Grads([gamma, beta], list(ctx.needs_input_grad[3:]))
+        dg = G.dst[0] if G.dst[0] is not None else torch.zeros_like(gamma)
+        db = G.dst[1] if G.dst[1] is not None else torch.zeros_like(beta)
+        dx = hip.graphnorm_bwd(_flat3(dy), ctx.x3, gamma.detach(), ctx.stats, dg, db, G.acc[0] and G.acc[1], ctx.eps)
+        return ((dx[0] if ctx.squeeze else dx), None, None) + G.out()
+
+
 class MeanAggFn(torch.autograd.Function):
     """SimpleConv(aggr="mean") (src/models.py:414)."""
 

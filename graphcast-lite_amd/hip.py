@@ -290,6 +290,28 @@ def layernorm_bwd(dy, x, gamma, stats, dgamma, dbeta, accumulate: bool):
     return dx
 
 
+def graphnorm_fwd(x3, gamma, beta, eps=1e-5):
+    B, n, F = x3.shape
+    y = torch.empty(B, n, F, dtype=torch.float32, device=x3.device)
+    stats = torch.empty(B, 2, dtype=torch.float32, device=x3.device)
+    nb = lib().gcl_graphnorm_ws_bytes(B, n, F)
+    ws = workspace(nb, x3.device)
+    _check(lib().gcl_graphnorm_fwd(_p(x3), x3.stride(1), x3.stride(0), _p(gamma), _p(beta), float(eps), _p(y), F, n * F,
+                                   _p(stats), B, n, F, ws.data_ptr(), ws.numel(), _stream()))
+    return y, stats
+
+
+def graphnorm_bwd(dy3, x3, gamma, stats, dgamma, dbeta, accumulate: bool, eps=1e-5):
+    B, n, F = x3.shape
+    dx = torch.empty(B, n, F, dtype=torch.float32, device=x3.device)
+    nb = lib().gcl_graphnorm_ws_bytes(B, n, F)
+    ws = workspace(nb, x3.device)
+    _check(lib().gcl_graphnorm_bwd(_p(dy3), dy3.stride(1), dy3.stride(0), _p(x3), x3.stride(1), x3.stride(0), _p(gamma),
+                                   _p(stats), float(eps), _p(dx), F, n * F, _p(dgamma), _p(dbeta),
+                                   1 if accumulate else 0, B, n, F, ws.data_ptr(), ws.numel(), _stream()))
+    return dx
+
+
 def colsum(x, out, accumulate: bool):
     rows, F = x.shape
     nb = lib().gcl_colsum_ws_bytes(rows, F)

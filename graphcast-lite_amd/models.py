@@ -37,7 +37,7 @@ from .config import (
     PipelineConfig,
 )
 from .create_graphs import create_decoding_graph, create_encoding_graph, create_processing_graph
-from .functional import AssembleFn, GATLayerFn, Gather2Fn, GCNStackFn, LayerNormFn, MeanAggFn, MLPFn
+from .functional import AssembleFn, GATLayerFn, Gather2Fn, GCNStackFn, GraphNormFn, LayerNormFn, MeanAggFn, MLPFn
 from .mesh import get_hierarchy_of_triangular_meshes_for_sphere, get_mesh_lat_long, prune_mesh_to_region
 
 
@@ -86,10 +86,11 @@ class LayerNorm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(in_channels))
 
     def forward(self, x):
-        if self.mode != "node":
-            raise NotImplementedError(
-                'LayerNorm(mode="graph") is not on the HIP path yet (no BASELINE config uses it)')
-        return LayerNormFn.apply(x, self, self.eps, self.weight, self.bias)
+        if self.mode == "node":
+            return LayerNormFn.apply(x, self, self.eps, self.weight, self.bias)
+        if self.mode == "graph":
+            return GraphNormFn.apply(x, self, self.eps, self.weight, self.bias)
+        raise ValueError(f"Unknown normalization mode: {self.mode}")
 
 
 class GCNConv(nn.Module):
@@ -413,7 +414,12 @@ class WeatherPrediction(nn.Module):
     def _compact_eligible(self) -> bool:
         if os.environ.get("GCL_NO_COMPACT", "0") not in ("0", ""):
             return False
-        ok = lambda m: m.graph_layer.layer_type == GraphLayerType.ConvGCN
+        def ok(m):
+            # graph-mode LayerNorm statistics couple every row of a sample, so no row of that stage
+            # may be dropped or shared across the batch
+            node_ln = all(ln.mode == "node" for ln in m.modules() if isinstance(ln, LayerNorm))
+            return m.graph_layer.layer_type == GraphLayerType.ConvGCN and node_ln
+
         return ok(self.encoder) and ok(self.decoder) and getattr(self, "compact", True)
 
     def _compact_setup(self, device):

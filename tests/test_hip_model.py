@@ -111,6 +111,35 @@ def test_general_path_matches_compact_path(levels, B):
         assert d <= 2e-5 * float(gc[n_].double().norm()) + 1e-6 * gn, n_
 
 
+def test_graph_mode_layernorm_model():
+    """A pipeline whose MLP and processor use layer_norm_mode="graph" (SURVEY.md §8a row 9)."""
+    from graphcast_lite_amd.models import WeatherPrediction
+    from graphcast_lite_amd.train import batch_loss
+
+    cfg = experiment("baseline", mesh_levels=[1, 2])
+    cfg.pipeline.encoder.mlp.layer_norm_mode = "graph"
+    cfg.pipeline.processor.gcn.layer_norm_mode = "graph"
+    torch.manual_seed(7)
+    lats, lons = np.linspace(-90, 90, 32), np.linspace(0, 360, 64, endpoint=False)
+    m = WeatherPrediction((lats, lons), cfg.graph, cfg.pipeline, cfg.data, torch.device(DEV))
+    o = omodel.WeatherPrediction(
+        cfg.pipeline, cfg.data, num_grid_nodes=m._num_grid_nodes, num_mesh_nodes=m._num_mesh_nodes,
+        encoding_graph=m.encoding_graph.cpu(), processing_graph=m.processing_graph.cpu(),
+        decoding_graph=m.decoding_graph.cpu(), init_grid_features=m.init_grid_features.cpu(),
+        init_mesh_features=m.init_mesh_features.cpu(), processing_edge_features=m._processing_edge_features.cpu())
+    o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    m.compact = False  # graph-mode statistics couple all rows of a sample: no row may be dropped or shared
+    X, y = data(cfg, m._num_grid_nodes, 2)
+    assert rel(m(X.to(DEV)), o(X)) < 1e-5
+    T.train_step_loss(o, X, y).backward()
+    batch_loss(m, X.to(DEV), y.to(DEV)).backward()
+    og = dict(o.named_parameters())
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in og.values())))
+    for n_, p in m.named_parameters():
+        d = float((p.grad.double().cpu() - og[n_].grad.double()).norm())
+        assert d <= 1e-4 * float(og[n_].grad.double().norm()) + 1e-6 * gn, n_
+
+
 def test_batch_one_follows_reference_squeeze():
     cfg, m, o = make_pair("baseline", [1, 2])
     X, _ = data(cfg, m._num_grid_nodes, 1)

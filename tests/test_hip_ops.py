@@ -211,6 +211,24 @@ def test_layernorm(hip, rows, F):
     assert rel(dx, x.grad) < 2e-5 and rel(dg, gm.grad) < 2e-5 and rel(db, bt.grad) < TOL
 
 
+@pytest.mark.parametrize("B,n,F", [(3, 500, 64), (1, 162, 33), (2, 3000, 128), (2, 7, 12)])
+def test_graphnorm(hip, B, n, F):
+    """PyG LayerNorm(mode="graph"): per-sample statistics over all n*F elements, eps added to the std."""
+    x = (rnd(B, n, F, seed=1) * 2 + 0.5).requires_grad_()
+    gm = (torch.rand(F, generator=torch.Generator().manual_seed(2)) + 0.5).requires_grad_()
+    bt = rnd(F, seed=3).requires_grad_()
+    dy = rnd(B, n, F, seed=4)
+    ref = P.pyg_layer_norm(x, gm, bt, "graph")
+    ref.backward(dy)
+    y, stats = hip.graphnorm_fwd(x.detach().to(DEV), gm.detach().to(DEV), bt.detach().to(DEV))
+    assert rel(y, ref) < TOL
+    dg, db = torch.empty(F, device=DEV), torch.empty(F, device=DEV)
+    dx = hip.graphnorm_bwd(dy.to(DEV), x.detach().to(DEV), gm.detach().to(DEV), stats, dg, db, False)
+    assert rel(dx, x.grad) < 2e-5 and rel(dg, gm.grad) < 2e-5 and rel(db, bt.grad) < TOL
+    const = hip.graphnorm_fwd(torch.full((1, 5, F), 2.5, device=DEV), gm.detach().to(DEV), bt.detach().to(DEV))[0]
+    assert rel(const[0], bt.detach().expand(5, F)) < 1e-6  # 0 / (0 + eps)
+
+
 @pytest.mark.parametrize("rows,F", [(1000, 64), (13, 33), (5000, 128)])
 def test_colsum(hip, rows, F):
     x = rnd(rows, F, seed=1)
