@@ -43,8 +43,11 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned off
   return make_float4(__builtin_bit_cast(float, v.x), __builtin_bit_cast(float, v.y), __builtin_bit_cast(float, v.z),
                      __builtin_bit_cast(float, v.w));
 }
+#ifndef GCL_ST_AUX
+#define GCL_ST_AUX 0  // cache-policy bits of the streamed-out stores (2 = nt)
+#endif
 __device__ __forceinline__ void buf_st1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, GCL_ST_AUX);
 }
 // Zero page for masked loads: an out-of-range lane reads from here instead of branching around
 // its load (pointer select + unconditional plain load keeps global_load_dwordx4 and no branch).
@@ -702,28 +705,6 @@ __global__ __launch_bounds__(256, 1) void linear_bwd_fused_kernel(
   if (part_slope && tid == 0) part_slope[blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
 }
 
-// out[i*ldo + j] (+)= sum_p part[p*pstride + i*pld + j]   for i < R, j < C.
-// 64 outputs per block, 4 thread groups split the partials, combined through LDS (fixed order).
-__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int32_t nparts,
-                                                           int64_t pstride, int32_t pld, float* __restrict__ out,
-                                                           int32_t ldo, int32_t R, int32_t C, int32_t accumulate) {
-  __shared__ float red[4][64];
-  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + e;
-  const bool ok = idx < R * C;
-  const int i = ok ? idx / C : 0, j = ok ? idx - i * C : 0;
-  float s = 0.f;
-  if (ok)
-    for (int p = g; p < nparts; p += 4) s += part[(size_t)p * pstride + (size_t)i * pld + j];
-  red[g][e] = s;
-  __syncthreads();
-  if (g == 0 && ok) {
-    const float tot = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-    float* o = out + (size_t)i * ldo + j;
-    *o = accumulate ? *o + tot : tot;
-  }
-}
-
 __global__ void reduce_scalar_kernel(const double* __restrict__ part, int32_t nparts, float* __restrict__ out) {
   // single wave; fixed order => deterministic
   double s = 0.0;
@@ -799,7 +780,6 @@ bool use_valu() {
   return v == 1;
 }
 
-constexpr int kMaxPersistentBlocks = 1024;
 constexpr int kDwBlocks = 512;
 
 struct LinGeom {

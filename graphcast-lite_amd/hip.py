@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgcl_hip.so")
+LIB_PATH = os.environ.get("GCL_LIB") or os.path.join(_HERE, "libgcl_hip.so")  # GCL_LIB: A/B builds while tuning
 
 GRAPH_GCN, GRAPH_GAT, GRAPH_MEAN = 0, 1, 2
 
