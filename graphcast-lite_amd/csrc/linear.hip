@@ -705,6 +705,181 @@ __global__ __launch_bounds__(256, 1) void linear_bwd_fused_kernel(
   if (part_slope && tid == 0) part_slope[blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused backward, 64-wide input panel (Fin in 33..64), 64-row tiles: 50 KB of LDS per block, so
+// THREE blocks (12 waves) share a CU instead of one - the loads of one block hide behind the MFMAs
+// of the others.  Waves are (row group rg = w&1, column slab sg = w>>1): wave (rg,sg) computes the
+// dX slice rows 32rg.. x columns 32sg.., and dW tile w (of NO x 2) over the tile's 64 rows.
+// Same partial-record layout and outputs as linear_bwd_fused_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int NO>
+__global__ __launch_bounds__(256, 3) void linear_bwd_fused64_kernel(
+    const float* __restrict__ dY, int64_t lddy, const float* __restrict__ W, const float* __restrict__ P,
+    int64_t ldp, const float* __restrict__ in_slope, float* __restrict__ dX, int64_t lddx, int64_t rows, int32_t Fin,
+    int32_t Fout, float* __restrict__ part_dw, float* __restrict__ part_db, float* __restrict__ part_cs,
+    double* __restrict__ part_slope) {
+  constexpr int NC = 2;
+  constexpr int FoP = NO * 32, FiP = NC * 32;
+  constexpr int KPo = FoP + 2;
+  constexpr int TM = 64;
+  constexpr int NT = NO * NC;
+  constexpr int CY = FoP / 4, CP = FiP / 4;     // float4 columns per row (8|16, 16)
+  constexpr int RY = 64 / CY, RP = 64 / CP;     // rows per wave-instruction
+  constexpr int NY = 16 / RY, NP = 16 / RP;     // wave-instructions per 16-row slice
+  extern __shared__ __align__(16) float smem[];
+  float* Wt = smem;               // [FiP][KPo]
+  float* dYl = Wt + FiP * KPo;    // [TM][KPo]
+  float* Pl = dYl + TM * KPo;     // [TM][FiP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const int rg = wave & 1, sg = wave >> 1;
+
+  for (int idx = tid; idx < FiP * FoP; idx += 256) {
+    const int c = idx / FoP, o = idx - c * FoP;
+    Wt[c * KPo + o] = (c < Fin && o < Fout) ? W[(int64_t)o * Fin + c] : 0.f;
+  }
+  const bool act = in_slope != nullptr;
+  const float slope = act ? *in_slope : 1.f;
+  const int64_t ntiles = (rows + TM - 1) / TM;
+
+  f32x16 dw;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dw[r] = 0.f;
+  float dbacc = 0.f, cs = 0.f;
+  double slope_acc = 0.0;
+  const bool has_tile = wave < NT;
+  const int so = wave % NO, sc = wave / NO;
+
+  const int ysub = lane / CY, ycol = lane % CY, psub = lane / CP, pcol = lane % CP;
+  float4 pre[NY + NP];
+  const float4* zero = gcl_zero4;
+  auto issue = [&](int64_t tile) {
+    const int64_t r0 = tile * TM + wave * 16;
+#pragma unroll
+    for (int it = 0; it < NY; ++it) {
+      const int64_t row = r0 + it * RY + ysub;
+      const bool ok = (ycol * 4 < Fout) && (row < rows);
+      pre[it] = *(ok ? reinterpret_cast<const float4*>(dY + row * lddy + ycol * 4) : zero);
+    }
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const int64_t row = r0 + it * RP + psub;
+      const bool ok = (pcol * 4 < Fin) && (row < rows);
+      pre[NY + it] = *(ok ? reinterpret_cast<const float4*>(P + row * ldp + pcol * 4) : zero);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < NY; ++it) {
+      const int r = wave * 16 + it * RY + ysub;
+      float2* d = reinterpret_cast<float2*>(dYl + r * KPo + ycol * 4);
+      const float4 v = pre[it];
+      d[0] = make_float2(v.x, v.y);
+      d[1] = make_float2(v.z, v.w);
+    }
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const int r = wave * 16 + it * RP + psub;
+      *reinterpret_cast<float4*>(Pl + r * FiP + pcol * 4) = pre[NY + it];
+    }
+  };
+
+  issue(blockIdx.x);
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    issue(t + gridDim.x);
+
+    const int64_t r0 = t * TM;
+    const int64_t nr = (rows - r0) < TM ? (rows - r0) : TM;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(dX + r0 * lddx, win_bytes(nr, lddx, Fin));
+
+    // ---- dX slice: rows 32rg.., columns 32sg.. ----
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+      const float* ap = dYl + (rg * 32 + li) * KPo + 2 * lk;
+      const float* bp = Wt + (sg * 32 + li) * KPo + 2 * lk;
+      constexpr int nq = FoP / 4;
+      float2 a_c = *reinterpret_cast<const float2*>(ap);
+      float2 b_c = *reinterpret_cast<const float2*>(bp);
+#pragma unroll 4
+      for (int q = 0; q < nq; ++q) {
+        const int qn = (q + 1 < nq) ? q + 1 : q;
+        const float2 a_n = *reinterpret_cast<const float2*>(ap + qn * 4);
+        const float2 b_n = *reinterpret_cast<const float2*>(bp + qn * 4);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c.x, b_c.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c.y, b_c.y, acc, 0, 0, 0);
+        a_c = a_n;
+        b_c = b_n;
+      }
+    }
+    {
+      const int j = sg * 32 + li;
+      const bool jok = j < Fin;
+      float zv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zv[r] = Pl[(rg * 32 + d_row(r, lane)) * FiP + j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = rg * 32 + d_row(r, lane);
+        float v = acc[r];
+        const bool neg = act && (zv[r] <= 0.f);
+        slope_acc += neg ? (double)(v * zv[r]) : 0.0;
+        v = neg ? v * slope : v;
+        cs += v;
+        buf_st1(rx, jok ? (unsigned)((rr * lddx + j) * 4) : kOOB, v);
+      }
+    }
+
+    // ---- dW tile of this wave over the 64 rows of the tile ----
+    if (has_tile) {  // wave-uniform
+      const float* yp = dYl + lk * KPo + so * 32 + li;
+      const float* xp = Pl + lk * FiP + sc * 32 + li;
+      float av = yp[0], bv = xp[0];
+#pragma unroll 4
+      for (int k = 0; k < TM; k += 2) {
+        const int kn = (k + 2 < TM) ? k + 2 : k;
+        const float an = yp[kn * KPo];
+        const float bn = xp[kn * FiP];
+        const float bx = act ? gcl::prelu_f(bv, slope) : bv;
+        dbacc += av;
+        dw = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bx, dw, 0, 0, 0);
+        av = an;
+        bv = bn;
+      }
+    }
+  }
+
+  constexpr size_t REC = (size_t)FoP * FiP + FoP + FiP;
+  float* out = part_dw + (size_t)blockIdx.x * REC;
+  if (has_tile) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(size_t)(so * 32 + d_row(r, lane)) * FiP + sc * 32 + li] = dw[r];
+    if (part_db && sc == 0) {
+      const float d = dbacc + __shfl_xor(dbacc, 32, 64);
+      if (lane < 32) part_db[(size_t)blockIdx.x * REC + so * 32 + lane] = d;
+    }
+  }
+  __syncthreads();
+  float* red = smem;  // [4][32]
+  {
+    const float v = cs + __shfl_xor(cs, 32, 64);
+    if (lane < 32) red[wave * 32 + lane] = v;
+  }
+  for (int off = 32; off > 0; off >>= 1) slope_acc += __shfl_down(slope_acc, off, 64);
+  double* dred = reinterpret_cast<double*>(smem + 4 * 32);
+  if (lane == 0) dred[wave] = slope_acc;
+  __syncthreads();
+  if (part_cs && tid < FiP) {
+    const int s2 = tid >> 5, c = tid & 31;  // column slab s2 is held by waves 2*s2 (rg 0) and 2*s2+1 (rg 1)
+    part_cs[(size_t)blockIdx.x * REC + tid] = red[(2 * s2) * 32 + c] + red[(2 * s2 + 1) * 32 + c];
+  }
+  if (part_slope && tid == 0) part_slope[blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
+}
+
 __global__ void reduce_scalar_kernel(const double* __restrict__ part, int32_t nparts, float* __restrict__ out) {
   // single wave; fixed order => deterministic
   double s = 0.0;
@@ -995,7 +1170,7 @@ static bool fused_ok(const float* dy, int64_t lddy, const float* x, int64_t ldx,
 
 extern "C" size_t gcl_linear_bwd_all_ws_bytes(int64_t rows, int32_t Fin, int32_t Fout) {
   const size_t FiP = (size_t)((Fin + 31) / 32) * 32, FoP = (size_t)((Fout + 31) / 32) * 32;
-  const size_t fused = (size_t)gcl::kNumCU * (FoP * FiP + FoP + FiP) * sizeof(float) + (size_t)gcl::kNumCU * 8 + 64;
+  const size_t fused = (size_t)3 * gcl::kNumCU * (FoP * FiP + FoP + FiP) * sizeof(float) + (size_t)3 * gcl::kNumCU * 8 + 64;
   size_t sep = gcl_linear_bwd_ws_bytes(rows, Fin, Fout);
   const size_t cs = gcl_colsum_ws_bytes(rows, Fin);
   if (cs > sep) sep = cs;
@@ -1020,19 +1195,35 @@ extern "C" int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W,
   }
   const int NO = (Fout + 31) / 32, NC = (Fin + 31) / 32;
   const int FoP = NO * 32, FiP = NC * 32;
-  const int64_t ntiles = gcl::cdiv(rows, 128);
-  const int nblk = (int)(ntiles < gcl::kNumCU ? ntiles : gcl::kNumCU);
+  static const int no64 = [] { const char* e = getenv("GCL_NO_FUSED64"); return (e && atoi(e)) ? 1 : 0; }();
+  const bool use64 = (NC == 2) && !no64;  // 64-row tiles, 3 blocks per CU
+  const int64_t ntiles = gcl::cdiv(rows, use64 ? 64 : 128);
+  const int64_t cap = use64 ? 3 * gcl::kNumCU : gcl::kNumCU;
+  const int nblk = (int)(ntiles < cap ? ntiles : cap);
   const size_t rec_f = (size_t)FoP * FiP + FoP + FiP;  // floats per block record
   float* part_dw = (float*)ws;
   float* part_db = part_dw + (size_t)FoP * FiP;
   float* part_cs = part_db + FoP;
-  double* part_sl = (double*)(((uintptr_t)(part_dw + (size_t)gcl::kNumCU * rec_f) + 15) & ~(uintptr_t)15);
-  const size_t lds = ((size_t)FiP * (FoP + 2) + 128 * (size_t)(FoP + 2) + 128 * (size_t)FiP) * sizeof(float);
+  double* part_sl = (double*)(((uintptr_t)(part_dw + (size_t)3 * gcl::kNumCU * rec_f) + 15) & ~(uintptr_t)15);
   const bool want_slope = in_slope && d_in_slope;
+  if (use64) {
+    const size_t lds64 = ((size_t)FiP * (FoP + 2) + 64 * (size_t)(FoP + 2) + 64 * (size_t)FiP) * sizeof(float);
+#define GCL_FB64(NO_)                                                                                             \
+  do {                                                                                                            \
+    auto kern = linear_bwd_fused64_kernel<NO_>;                                                                   \
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds64, st, dy, lddy, W, x, ldx, in_slope, dx, lddx, rows, Fin, \
+                       Fout, part_dw, db ? part_db : nullptr, colsum_dx ? part_cs : nullptr,                      \
+                       want_slope ? part_sl : nullptr);                                                           \
+  } while (0)
+    if (NO == 1) GCL_FB64(1);
+    else GCL_FB64(2);
+#undef GCL_FB64
+  } else {
+  const size_t lds = ((size_t)FiP * (FoP + 2) + 128 * (size_t)(FoP + 2) + 128 * (size_t)FiP) * sizeof(float);
 #define GCL_FB(NO_, NC_)                                                                                          \
   do {                                                                                                            \
     auto kern = linear_bwd_fused_kernel<NO_, NC_>;                                                                \
-    { static bool lds_set = false;                                                                          \
+    { static bool lds_set = false;                                                                                \
       if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, dy, lddy, W, x, ldx, in_slope, dx, lddx, rows, Fin,  \
                        Fout, part_dw, db ? part_db : nullptr, colsum_dx ? part_cs : nullptr,                      \
@@ -1045,6 +1236,7 @@ extern "C" int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W,
   else if (NO == 2 && NC == 2) GCL_FB(2, 2);
   else GCL_FB(2, 3);
 #undef GCL_FB
+  }
   GCL_CHECK_LAUNCH();
   {
     // per-block record: [dW tile FoP*FiP | db FoP | colsum FiP]; one launch reduces all three
