@@ -158,9 +158,28 @@ class SparseGATConv(GATConv):
         if batch_num == 0:
             print("edge_index", torch.Size([2, g.e]))
             new_ei = hip.gat_prune(g, alpha, float(attention_threshold)).to(x.device)
+            new_ei = _broadcast_edges_from_rank0(new_ei)  # C2: every rank keeps rank 0's pruned graph
             mask = alpha >= attention_threshold
             return out, (new_ei, alpha[mask])
         return out, (g.edges_with_loops(x.device), alpha)
+
+
+def _broadcast_edges_from_rank0(edge_index: torch.Tensor) -> torch.Tensor:
+    """Collective C2: under data parallelism each rank sees different samples, so the
+    attention-based prune decision (taken from sample 0 of batch 0, src/models.py:138-149) would
+    differ per rank; rank 0's surviving edge list is broadcast (count first, then the int64 list)
+    so that all ranks rebuild the same CSR.  No-op in single-process runs."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return edge_index
+    dev = edge_index.device
+    count = torch.tensor([edge_index.shape[1]], dtype=torch.int64, device=dev)
+    dist.broadcast(count, src=0)
+    k = int(count.item())
+    buf = edge_index.contiguous() if dist.get_rank() == 0 else torch.empty(2, k, dtype=torch.int64, device=dev)
+    dist.broadcast(buf, src=0)
+    return buf
 
 
 class SimpleConv(nn.Module):

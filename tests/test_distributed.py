@@ -99,3 +99,30 @@ def test_shard_batch_rejects_uneven_split():
         shard_batch(X, y, 0, 2)
     a, b = shard_batch(torch.arange(8).view(8, 1, 1), torch.arange(8).view(8, 1, 1), 1, 4)
     assert a.flatten().tolist() == [2, 3]
+
+
+def _bcast_worker(rank, world, port, out_dir):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from graphcast_lite_amd.models import _broadcast_edges_from_rank0
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # every rank pruned differently (different samples); all must end with rank 0's list
+    mine = torch.arange(2 * (5 + 3 * rank), dtype=torch.int64).view(2, -1) + 100 * rank
+    got = _broadcast_edges_from_rank0(mine)
+    torch.save(got, os.path.join(out_dir, f"edges_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sparse_gat_prune_broadcast_c2(tmp_path):
+    """C2: the pruned processing graph of rank 0 reaches every rank (different list lengths)."""
+    from graphcast_lite_amd.models import _broadcast_edges_from_rank0
+
+    port = _free_port()
+    mp.spawn(_bcast_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    e0, e1 = torch.load(os.path.join(tmp_path, "edges_0.pt")), torch.load(os.path.join(tmp_path, "edges_1.pt"))
+    assert torch.equal(e0, torch.arange(10, dtype=torch.int64).view(2, 5)) and torch.equal(e0, e1)
+    x = torch.zeros(2, 3, dtype=torch.int64)
+    assert _broadcast_edges_from_rank0(x) is x  # single process: untouched
