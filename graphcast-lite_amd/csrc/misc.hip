@@ -172,6 +172,41 @@ __global__ __launch_bounds__(256) void gather2_kernel(const float* __restrict__ 
   }
 }
 
+// One autoregressive advance (scripts/predict.py:512-535, src/train.py:203-228): residual add,
+// static / forcing channel overwrite, output append and window shift in ONE pass.
+//   step_out = residual ? state[..., obs-1, :] + delta : delta
+//   step_out[c] = state[..., obs-1, c] for static channels, y_step[c] for forcing channels
+//   out[b, g, out_off + c] = step_out;  new_state[..., k, :] = state[..., k+1, :], last slot = step_out
+// chan_kind[c]: 0 = predicted, 1 = static (carry forward), 2 = forcing (from y_step when given).
+__global__ __launch_bounds__(256) void ar_advance_kernel(const float* __restrict__ state,
+                                                         const float* __restrict__ delta,
+                                                         const float* __restrict__ y_step, int64_t ldy, int64_t bsy,
+                                                         const int32_t* __restrict__ chan_kind,
+                                                         float* __restrict__ new_state, float* __restrict__ out,
+                                                         int64_t ldo, int64_t bso, int32_t out_off, int32_t B,
+                                                         int32_t G, int32_t obs, int32_t C, int32_t residual) {
+  const int64_t total = (int64_t)B * G * obs * C;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const int k = (int)((idx / C) % obs);
+    const int64_t bg = idx / ((int64_t)C * obs);
+    if (k < obs - 1) {
+      new_state[idx] = state[idx + C];  // shift the window by one step
+    } else {
+      const int g = (int)(bg % G);
+      const int64_t b = bg / G;
+      const float xl = state[idx];
+      float v = delta[bg * C + c];
+      if (residual) v += xl;
+      const int kind = chan_kind ? chan_kind[c] : 0;
+      if (kind == 1) v = xl;
+      else if (kind == 2 && y_step) v = y_step[b * bsy + (int64_t)g * ldy + c];
+      new_state[idx] = v;
+      if (out) out[b * bso + (int64_t)g * ldo + out_off + c] = v;
+    }
+  }
+}
+
 inline unsigned grid_for(int64_t total, int cap = 4096) {
   int64_t nb = gcl::cdiv(total > 0 ? total : 1, 256);
   return (unsigned)(nb > cap ? cap : nb);
@@ -268,6 +303,21 @@ extern "C" int gcl_adam_step_dev(float* p, const float* g, float* m, float* v, i
   if (count > 0)
     hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(count, 1024)), dim3(256), 0, st, p, g, m, v, count, lr, beta1,
                        beta2, eps, weight_decay, bc_dev, grad_scale);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+extern "C" int gcl_ar_advance(const float* state, const float* delta, const float* y_step, int64_t ldy, int64_t bsy,
+                              const int32_t* chan_kind, float* new_state, float* out, int64_t ldo, int64_t bso,
+                              int32_t out_off, int32_t B, int32_t G, int32_t obs, int32_t C, int32_t residual,
+                              gcl_stream_t stream) {
+  GCL_CHECK_ARG(state && delta && new_state, "ar_advance: null argument");
+  GCL_CHECK_ARG(state != new_state, "ar_advance: the window shift cannot be done in place");
+  GCL_CHECK_ARG(B > 0 && G > 0 && obs >= 1 && C > 0, "ar_advance: bad shape");
+  GCL_CHECK_ARG(!out || (ldo >= out_off + C), "ar_advance: output row too short for out_off + C");
+  const int64_t total = (int64_t)B * G * obs * C;
+  hipLaunchKernelGGL(ar_advance_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, state, delta,
+                     y_step, ldy, bsy, chan_kind, new_state, out, ldo, bso, out_off, B, G, obs, C, residual);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -63,6 +63,8 @@ _SIGNATURES = {
     "gcl_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     "gcl_adam_step_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _vp]),
     "gcl_copy_rows": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "gcl_ar_advance": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32,
+                                 _i32, _vp]),
     "gcl_gather2_rows": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
 }
 
@@ -423,3 +425,15 @@ def gather2_rows(a3, map_a, b3, map_b, nd: int, B: int, sum_batch: bool = False)
     _check(lib().gcl_gather2_rows(_p(a3), a3.stride(1), bsa, _pi(map_a), _p(b3), 0 if b3 is None else b3.stride(1),
                                   bsb, _pi(map_b), _p(out), F, nd * F, B, nd, F, 1 if sum_batch else 0, _stream()))
     return out
+
+
+def ar_advance(state4, delta3, y_step3, chan_kind, out3, out_off: int, residual: bool):
+    """state4 [B,G,obs,C] contiguous -> new state (same shape); appends the step to out3 [B,G,steps*C]."""
+    B, G, obs, Cc = state4.shape
+    new_state = torch.empty_like(state4)
+    _check(lib().gcl_ar_advance(
+        _p(state4), _p(delta3.contiguous()), _p(y_step3), y_step3.stride(1) if y_step3 is not None else 0,
+        y_step3.stride(0) if y_step3 is not None else 0, _pi(chan_kind), _p(new_state), _p(out3),
+        out3.stride(1) if out3 is not None else 0, out3.stride(0) if out3 is not None else 0, int(out_off), B, G, obs, Cc,
+        1 if residual else 0, _stream()))
+    return new_state

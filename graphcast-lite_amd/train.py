@@ -16,6 +16,50 @@ from . import hip
 from .functional import WeightedMSEFn
 
 
+class FileNames:
+    """File names of an experiment directory (src/constants.py:5-15)."""
+
+    EXPERIMENT_CONFIG = "config.json"
+    TRAIN_X = "X_train.pt"
+    TRAIN_Y = "y_train.pt"
+    TEST_X = "X_test.pt"
+    TEST_Y = "y_test.pt"
+    SAVED_MODEL = "best_model.pth"
+    SAVED_RESULTS = "results.json"
+    CHECKPOINT = "checkpoint.pth"
+
+
+def save_checkpoint(path, model, optimiser, epoch, ar_steps, best_val_loss, patience_counter, train_losses,
+                    val_losses):
+    """Same dictionary layout as the reference (src/train.py:22-34), so either side can resume the
+    other's `checkpoint.pth`; `best_model.pth` is a bare `model.state_dict()` (src/train.py:496)."""
+    torch.save({
+        "epoch": epoch,
+        "ar_steps": ar_steps,
+        "best_val_loss": best_val_loss,
+        "patience_counter": patience_counter,
+        "train_losses": train_losses,
+        "val_losses": val_losses,
+        "model_state_dict": model.state_dict(),
+        "optimizer_state_dict": optimiser.state_dict(),
+    }, path)
+
+
+def load_checkpoint(path, model, optimiser, device):
+    """src/train.py:37-49.  `weights_only=True`: nothing from the file is executed."""
+    ckpt = torch.load(path, map_location=device, weights_only=True)
+    model.load_state_dict(ckpt["model_state_dict"])
+    optimiser.load_state_dict(ckpt["optimizer_state_dict"])
+    return {
+        "start_epoch": ckpt["epoch"] + 1,
+        "ar_steps": ckpt["ar_steps"],
+        "best_val_loss": ckpt["best_val_loss"],
+        "patience_counter": ckpt["patience_counter"],
+        "train_losses": ckpt["train_losses"],
+        "val_losses": ckpt["val_losses"],
+    }
+
+
 def get_lat_weights(lat_dim, lon_dim, device, flat_lats=None):
     """cos(lat)/mean laid out as the reference lays it out (src/train.py:53-72), `[1, G, 1]`."""
     if flat_lats is not None:

@@ -228,6 +228,17 @@ int gcl_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t coun
 int gcl_copy_rows(const float* src, int64_t lds, int64_t bss, float* dst, int64_t ldd, int64_t bsd,
                   int32_t B, int32_t rows, int32_t F, gcl_stream_t stream);
 
+/* One autoregressive advance of the observation window, fused (scripts/predict.py:512-535 and the
+ * same steps in src/train.py:203-228): step_out = residual ? x_last + delta : delta; static channels
+ * (chan_kind 1) carry x_last forward, forcing channels (chan_kind 2) take y_step when it is given;
+ * step_out is appended to `out` at column out_off (out may be NULL) and the window
+ * state [B,G,obs,C] is shifted by one step into new_state (must not alias state).
+ * state / delta / new_state are contiguous; y_step and out are addressed with (ld, bs). */
+int gcl_ar_advance(const float* state, const float* delta, const float* y_step, int64_t ldy, int64_t bsy,
+                   const int32_t* chan_kind, float* new_state, float* out, int64_t ldo, int64_t bso,
+                   int32_t out_off, int32_t B, int32_t G, int32_t obs, int32_t C, int32_t residual,
+                   gcl_stream_t stream);
+
 /* Row gather from up to two sources (stage glue of src/models.py:837-838,860-862 restricted to the
  * rows that matter):  dst[b,i,:] = a[b, map_a[i], :] if map_a[i] >= 0 (map_a NULL = identity), else
  * b[b, map_b[i], :] if map_b[i] >= 0, else 0.  A source with batch stride 0 is broadcast.

@@ -72,3 +72,28 @@ def train_step_loss(model, X, y, *, lat_weights=None, channel_mask=None, spatial
                 out[:, :, ch] = y_steps[:, :, s, ch]
         state = torch.cat([state[:, :, 1:, :], out.unsqueeze(2)], dim=2)
     return loss / steps
+
+
+@torch.no_grad()
+def ar_rollout(model, X, ar_steps, y=None, static_channels=None, forcing_channels=None, use_residual=True):
+    """AR branch of the reference's inference loop (`scripts/predict.py:499-538`), batched."""
+    B, G, _ = X.shape
+    obs = model.obs_window
+    C = X.shape[-1] // obs
+    state = X.view(B, G, obs, C)
+    y_steps = y.view(B, G, -1, C) if y is not None else None
+    outs = []
+    for s in range(ar_steps):
+        delta = model(X=state.reshape(B, G, -1), attention_threshold=0.0)
+        if delta.dim() == 2:
+            delta = delta.unsqueeze(0)
+        step_out = (state[:, :, -1, :] + delta) if use_residual else delta.clone()
+        if static_channels:
+            for ch in static_channels:
+                step_out[:, :, ch] = state[:, :, -1, ch]
+        if forcing_channels and y_steps is not None and s < y_steps.shape[2]:
+            for ch in forcing_channels:
+                step_out[:, :, ch] = y_steps[:, :, s, ch]
+        outs.append(step_out)
+        state = torch.cat([state[:, :, 1:, :], step_out.unsqueeze(2)], dim=2)
+    return torch.cat(outs, dim=-1)

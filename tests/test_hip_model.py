@@ -252,3 +252,99 @@ def test_state_dict_round_trip_with_reference_keys():
     assert not [k for k in res.missing_keys if "lin" in k]
     assert "processor.graph_layer.layers.1.weight" in m.state_dict()  # alias of the shared PReLU
     assert m.processor.graph_layer.layers[1] is m.processor.graph_layer.activation
+
+
+@pytest.mark.parametrize("obs,C,B,static,forcing,residual,with_y", [
+    (2, 5, 3, [1], [3, 4], True, True), (2, 5, 2, None, None, False, False), (1, 4, 2, [0, 2], [2], True, True),
+    (3, 7, 1, [6], [0], True, False)])
+def test_ar_advance_kernel(obs, C, B, static, forcing, residual, with_y):
+    """gcl_ar_advance == the per-step glue of scripts/predict.py:512-535 (bit-exact: one add at most)."""
+    from graphcast_lite_amd import hip
+    from graphcast_lite_amd.predict import channel_kinds
+
+    G, steps, s = 37, 3, 1
+    g = torch.Generator().manual_seed(5)
+    state = torch.randn(B, G, obs, C, generator=g)
+    delta = torch.randn(B, G, C, generator=g)
+    y = torch.randn(B, G, steps * C, generator=g) if with_y else None
+    out = torch.full((B, G, steps * C), -7.0)
+    want = (state[:, :, -1] + delta) if residual else delta.clone()
+    for ch in static or []:
+        want[:, :, ch] = state[:, :, -1, ch]
+    if with_y:
+        for ch in forcing or []:
+            want[:, :, ch] = y[:, :, s * C + ch]
+    want_state = torch.cat([state[:, :, 1:], want.unsqueeze(2)], dim=2)
+    out_d = out.to(DEV)
+    yd = y.to(DEV)[:, :, s * C:(s + 1) * C] if with_y else None
+    new = hip.ar_advance(state.to(DEV), delta.to(DEV), yd, channel_kinds(C, static, forcing, DEV), out_d, s * C,
+                         residual)
+    assert torch.equal(new.cpu(), want_state)
+    assert torch.equal(out_d.cpu()[:, :, s * C:(s + 1) * C], want)
+    assert (out_d.cpu()[:, :, :s * C] == -7.0).all() and (out_d.cpu()[:, :, (s + 1) * C:] == -7.0).all()
+
+
+@pytest.mark.parametrize("name,levels", [("baseline", [1, 2]), ("wb2_512x256_19f_ar", [1, 2])])
+def test_rollout_matches_oracle(name, levels):
+    """AR inference caller (scripts/predict.py:499-538) on the device vs the oracle's restatement."""
+    from graphcast_lite_amd.predict import rollout
+
+    cfg, m, o = make_pair(name, levels)
+    G = m._num_grid_nodes
+    F = cfg.data.num_features_used
+    obs = m.obs_window
+    steps = 4
+    g = torch.Generator().manual_seed(77)
+    X = torch.randn(2, G, obs * F, generator=g)
+    y = torch.randn(2, G, 3 * F, generator=g)  # covers 3 of the 4 steps: the last keeps the model's forcing values
+    static, forcing = [F - 1], [0, 2]
+    m.eval(), o.eval()
+    got = rollout(m, X.to(DEV), steps, y=y.to(DEV), static_channels=static, forcing_channels=forcing)
+    want = T.ar_rollout(o, X, steps, y=y, static_channels=static, forcing_channels=forcing)
+    assert got.shape == (2, G, steps * F)
+    for s in range(steps):  # error compounds through the window; stays at fp32 round-off
+        assert rel(got[..., s * F:(s + 1) * F], want[..., s * F:(s + 1) * F]) < 1e-5, s
+    # carried / forced channels are exact copies
+    assert torch.equal(got[..., F - 1].cpu(), X[..., obs * F - 1])
+    assert torch.equal(got[..., F + 2].cpu(), y[..., F + 2])
+    # batch-1, 2-D input follows the reference's [G, AR*C] output
+    got1 = rollout(m, X[0].to(DEV), 2, use_residual=False)
+    want1 = T.ar_rollout(o, X[:1], 2, use_residual=False)[0]
+    assert got1.shape == (G, 2 * F) and rel(got1, want1) < 1e-5
+
+
+def test_checkpoint_resume_interchange(tmp_path):
+    """save/load_checkpoint keep the reference's dictionary (src/train.py:22-49): a checkpoint written
+    here loads into the oracle (reference-keyed) model and resumes torch.optim.Adam exactly."""
+    from graphcast_lite_amd.train import FileNames, load_checkpoint, save_checkpoint
+
+    cfg, m, o = make_pair("baseline", [1, 2])
+    G, F = m._num_grid_nodes, cfg.data.num_features_used
+    X, y = data(cfg, G, 2)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+
+    def one_step(model, optim):
+        optim.zero_grad()
+        loss = ((model(X=X.to(DEV)) + X.to(DEV)[..., F:] - y.to(DEV)) ** 2).mean()
+        loss.backward()
+        optim.step()
+        return loss.item()
+
+    one_step(m, opt)
+    path = tmp_path / FileNames.CHECKPOINT
+    save_checkpoint(path, m, opt, epoch=3, ar_steps=2, best_val_loss=0.5, patience_counter=1, train_losses=[1.0, 0.7],
+                    val_losses=[0.9])
+    raw = torch.load(path, weights_only=True)
+    assert set(raw) == {"epoch", "ar_steps", "best_val_loss", "patience_counter", "train_losses", "val_losses",
+                        "model_state_dict", "optimizer_state_dict"}
+    o.load_state_dict(raw["model_state_dict"], strict=True)  # reference-side load
+    after = one_step(m, opt)
+
+    cfg2, m2, _ = make_pair("baseline", [1, 2], seed=7)
+    opt2 = torch.optim.Adam(m2.parameters(), lr=1e-3)
+    st = load_checkpoint(path, m2, opt2, torch.device(DEV))
+    assert st == {"start_epoch": 4, "ar_steps": 2, "best_val_loss": 0.5, "patience_counter": 1,
+                  "train_losses": [1.0, 0.7], "val_losses": [0.9]}
+    assert one_step(m2, opt2) == after  # same weights + same Adam moments -> identical step
+    for a, b in zip(m.parameters(), m2.parameters()):
+        assert torch.equal(a, b)

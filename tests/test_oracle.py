@@ -191,3 +191,26 @@ def test_oracle_train_step_runs_all_configs():
         loss.backward()
         assert torch.isfinite(loss)
         assert all(p.grad is not None for n, p in m.named_parameters() if "activation" not in n or name != "sparse_attention")
+
+
+def test_ar_rollout_glue_semantics():
+    """oracle.train_step.ar_rollout against a hand-written model: window shift, residual, static and
+    forcing overwrites of scripts/predict.py:499-538."""
+    from oracle import train_step as T
+
+    class Toy(torch.nn.Module):
+        obs_window = 2
+
+        def forward(self, X, attention_threshold=0.0):
+            B, G, F2 = X.shape
+            C = F2 // 2
+            return X[..., :C] - X[..., C:]  # delta = older - newer
+
+    X = torch.tensor([[[1.0, 10.0, 100.0, 2.0, 20.0, 200.0]]])  # B=1,G=1,obs=2,C=3
+    y = torch.tensor([[[0.0, 0.0, 7.0]]])  # one known future step
+    out = T.ar_rollout(Toy(), X, 2, y=y, static_channels=[1], forcing_channels=[2])
+    # step 0: x_last=[2,20,200], delta=[-1,-10,-100] -> [1,10,100]; static ch1 <- 20; forcing ch2 <- 7
+    # step 1: window=[[2,20,200],[1,20,7]], delta=[1,0,193] -> [2,20,200]; static ch1 <- 20; no y left
+    assert out.tolist() == [[[1.0, 20.0, 7.0, 2.0, 20.0, 200.0]]]
+    out = T.ar_rollout(Toy(), X, 1, use_residual=False)
+    assert out.tolist() == [[[-1.0, -10.0, -100.0]]]
