@@ -191,11 +191,18 @@ class FlatParams:
     straight into the all-reduce bucket)."""
 
     def __init__(self, module: torch.nn.Module):
-        seen, self.params = set(), []
+        # `index[i]`: position of params[i] in module.parameters() - the index torch.optim.Adam(
+        # model.parameters()) gives it in its state_dict (frozen parameters keep their slot)
+        seen, self.params, self.index, pos = set(), [], [], 0
         for p in module.parameters():
-            if p.requires_grad and id(p) not in seen:
-                seen.add(id(p))
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            if p.requires_grad:
                 self.params.append(p)
+                self.index.append(pos)
+            pos += 1
+        self.num_module_params = pos
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
         self.flat = torch.empty(total, dtype=torch.float32, device=dev)
@@ -254,6 +261,45 @@ class FusedAdam:
 
     def zero_grad(self):
         self.flat.zero_grad()
+
+    def state_dict(self):
+        """The dictionary `torch.optim.Adam(model.parameters()).state_dict()` would hold after the
+        same steps (per-parameter `step / exp_avg / exp_avg_sq`), so `save_checkpoint` files written
+        from the fused optimiser resume under the reference's `load_checkpoint` (src/train.py:37-49)."""
+        t, state, off = self.t, {}, 0
+        for p, i in zip(self.flat.params, self.flat.index):
+            k = p.numel()
+            if t > 0:
+                state[i] = {"step": torch.tensor(float(t)), "exp_avg": self.m[off:off + k].view(p.shape).clone(),
+                            "exp_avg_sq": self.v[off:off + k].view(p.shape).clone()}
+            off += k
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": list(range(self.flat.num_module_params))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        """Inverse of `state_dict`; also accepts what torch.optim.Adam wrote for the same model."""
+        group = sd["param_groups"][0]
+        if group.get("amsgrad", False) or group.get("maximize", False):
+            raise ValueError("FusedAdam implements plain Adam only (amsgrad / maximize are not supported)")
+        self.lr, self.betas, self.eps = group["lr"], tuple(group["betas"]), group["eps"]
+        self.wd = group.get("weight_decay", 0.0)
+        steps, off = set(), 0
+        self.m.zero_(), self.v.zero_()
+        for p, i in zip(self.flat.params, self.flat.index):
+            k = p.numel()
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            if st is not None:
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state {i}: shape {tuple(st['exp_avg'].shape)} != {tuple(p.shape)}")
+                self.m[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+            off += k
+        if len(steps) > 1:
+            raise ValueError(f"FusedAdam keeps one step counter; the state holds several: {sorted(steps)}")
+        self.step_dev.fill_(steps.pop() if steps else 0)
 
 
 class TrainStep:
