@@ -47,6 +47,16 @@ constexpr int kEll = 8;      // stride of the ELL prefix arrays
 constexpr int kHeavy = 64;   // rows with more edges than this get a whole block
 
 __device__ __forceinline__ float prelu_f(float x, float a) { return x > 0.f ? x : a * x; }
+// Activation kinds of the dense kernels (GCL_ACT_* of gcl.h).  SiLU: x * sigmoid(x).
+constexpr int kActNone = 0, kActPrelu = 1, kActSilu = 2;
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+__device__ __forceinline__ float act_f(float x, float a, int kind) { return kind == kActSilu ? silu_f(x) : prelu_f(x, a); }
+// d act(z) / dz
+__device__ __forceinline__ float dsilu_f(float z) {
+  const float s = sigmoid_f(z);
+  return s * (1.f + z * (1.f - s));
+}
 
 // out[i*ldo + j] (+)= sum_p part[p*pstride + i*pld + j], i < R, j < C (parallel over partials, fixed order)
 int launch_reduce_parts(const float* part, int nparts, int64_t pstride, int pld, float* out, int ldo, int R, int C,

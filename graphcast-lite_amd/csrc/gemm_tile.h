@@ -1,0 +1,208 @@
+// Wide dense transforms:  Y = act(X) Wl^T (+ bias) (+ addend)   for K, N beyond what the
+// resident-panel kernel of linear.hip can hold in LDS (a 256x256 fp32 panel alone is 256 KiB).
+//
+// This is the dense work of the InteractionNet processor (src/models.py:166-236: edge / node MLPs
+// at latent 256) and of the 256-wide encoder / decoder MLPs of the v2 configs.  Classic tiled
+// contraction on the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32:
+//   block = 4 waves, 128 x 128 output tile, wave = 64 x 64 (2 x 2 MFMA tiles, 64 accumulators);
+//   K is walked in chunks of 32 through a double-buffered LDS stage ([128][34] + [128][34] floats
+//   per buffer = 68 KiB for both: two blocks per CU, two waves per SIMD);
+//   the global loads of chunk c+1 are issued before the 64 MFMAs of chunk c and committed to the
+//   other buffer after them: one barrier per chunk;
+//   fragments are 8-byte LDS reads (two k-steps each) at row stride 34 (stride/2 odd: conflict-free).
+// Tiles are dealt XCD-aware: the column tiles of one row tile get consecutive slots of the SAME
+// XCD, so the second read of an X tile hits that XCD's L2.
+// Included by linear.hip (same translation unit: shares its helpers and launch plumbing).
+#pragma once
+
+constexpr int kGtTM = 128, kGtTN = 128, kGtKC = 32, kGtKP = kGtKC + 2;
+constexpr size_t kGtLds = (size_t)2 * (kGtTM + kGtTN) * kGtKP * sizeof(float);
+
+// EPI_BIAS: akind/in_slope describe the activation applied to X on load.
+// EPI_DX  : X is dY (no activation), Wl = W^T (TRANS), akind/in_slope describe the activation whose
+//           derivative at Z multiplies the result; slope_part[block] gets the PReLU slope partial.
+template <int EPI, bool TRANS>
+__global__ __launch_bounds__(256, 2) void gemm_tile_kernel(
+    const float* __restrict__ X, int64_t ldx, int32_t akind, const float* __restrict__ in_slope,
+    const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy,
+    int64_t rows, int32_t K, int32_t N, const float* __restrict__ Z, int64_t ldz, const float* __restrict__ add,
+    int64_t ldadd, double* __restrict__ slope_part, int32_t nt, int64_t total, int32_t per_xcd) {
+  constexpr int TM = kGtTM, TN = kGtTN, KC = kGtKC, KP = kGtKP;
+  extern __shared__ __align__(16) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t L = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (L >= total) {  // block-uniform
+    if (EPI == EPI_DX && slope_part && tid == 0) slope_part[blockIdx.x] = 0.0;
+    return;
+  }
+  const int64_t r0 = (L / nt) * TM;
+  const int n0 = (int)(L % nt) * TN;
+  const float slope = in_slope ? *in_slope : 1.f;
+  const bool xact = EPI == EPI_BIAS && akind != gcl::kActNone;
+  const bool silu = akind == gcl::kActSilu;
+
+  float4 pre[8];  // [0..3] X, [4..7] W of the next chunk
+  const float4* zero = gcl_zero4;
+  auto issue = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 3, c4 = idx & 7;
+      const bool ok = (r0 + row < rows) && (k0 + 4 * c4 < K);
+      const float4* p = ok ? reinterpret_cast<const float4*>(X + (r0 + row) * ldx + k0 + 4 * c4) : zero;
+      pre[i] = *p;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;
+      if (TRANS) {
+        const int k = idx >> 5, j4 = idx & 31;
+        const bool ok = (k0 + k < K) && (n0 + 4 * j4 < N);
+        const float4* p = ok ? reinterpret_cast<const float4*>(W + (int64_t)(k0 + k) * ldw + n0 + 4 * j4) : zero;
+        pre[4 + i] = *p;
+      } else {
+        const int j = idx >> 3, c4 = idx & 7;
+        const bool ok = (n0 + j < N) && (k0 + 4 * c4 < K);
+        const float4* p = ok ? reinterpret_cast<const float4*>(W + (int64_t)(n0 + j) * ldw + k0 + 4 * c4) : zero;
+        pre[4 + i] = *p;
+      }
+    }
+  };
+  auto commit = [&](float* buf) {
+    float* Xl = buf;
+    float* Wl = buf + TM * KP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 3, c4 = idx & 7;
+      float4 v = pre[i];
+      if (xact) {
+        v.x = gcl::act_f(v.x, slope, akind); v.y = gcl::act_f(v.y, slope, akind);
+        v.z = gcl::act_f(v.z, slope, akind); v.w = gcl::act_f(v.w, slope, akind);
+      }
+      float2* d = reinterpret_cast<float2*>(Xl + row * KP + 4 * c4);
+      d[0] = make_float2(v.x, v.y);
+      d[1] = make_float2(v.z, v.w);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;
+      const float4 v = pre[4 + i];
+      if (TRANS) {
+        const int k = idx >> 5, j4 = idx & 31;
+        float* d = Wl + (4 * j4) * KP + k;
+        d[0] = v.x; d[KP] = v.y; d[2 * KP] = v.z; d[3 * KP] = v.w;
+      } else {
+        const int j = idx >> 3, c4 = idx & 7;
+        float2* d = reinterpret_cast<float2*>(Wl + j * KP + 4 * c4);
+        d[0] = make_float2(v.x, v.y);
+        d[1] = make_float2(v.z, v.w);
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nchunks = (K + KC - 1) / KC;
+  issue(0);
+  commit(smem);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    float* buf = smem + (size_t)(c & 1) * (TM + TN) * KP;
+    if (c + 1 < nchunks) issue((c + 1) * KC);  // block-uniform
+    const float* ap = buf + (wm * 64 + (lane & 31)) * KP + 2 * (lane >> 5);
+    const float* bp = buf + TM * KP + (wn * 64 + (lane & 31)) * KP + 2 * (lane >> 5);
+#pragma unroll
+    for (int q = 0; q < KC / 4; ++q) {
+      const float2 a0 = *reinterpret_cast<const float2*>(ap + 4 * q);
+      const float2 a1 = *reinterpret_cast<const float2*>(ap + 32 * KP + 4 * q);
+      const float2 b0 = *reinterpret_cast<const float2*>(bp + 4 * q);
+      const float2 b1 = *reinterpret_cast<const float2*>(bp + 32 * KP + 4 * q);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[1][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[1][1], 0, 0, 0);
+    }
+    if (c + 1 < nchunks) commit(smem + (size_t)((c + 1) & 1) * (TM + TN) * KP);
+    __syncthreads();
+  }
+
+  // epilogue: lane owns column j and 16 rows of each of its 4 MFMA tiles; branch-free accesses
+  const int64_t nr = (rows - r0) < TM ? (rows - r0) : TM;
+  const int ncols = (N - n0) < TN ? (N - n0) : TN;
+  const bool has_z = EPI == EPI_DX && Z != nullptr;
+  const bool has_add = add != nullptr;
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(Y + r0 * ldy + n0, win_bytes(nr, ldy, ncols));
+  const __amdgpu_buffer_rsrc_t rz = make_rsrc(has_z ? Z + r0 * ldz + n0 : Y, has_z ? win_bytes(nr, ldz, ncols) : 0);
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(has_add ? add + r0 * ldadd + n0 : Y, has_add ? win_bytes(nr, ldadd, ncols) : 0);
+  double slope_acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wn * 64 + j * 32 + (lane & 31);
+      const bool jok = col < ncols;
+      const float bj = (EPI == EPI_BIAS && bias && jok) ? bias[n0 + col] : 0.f;
+      float zv[16], av[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = wm * 64 + i * 32 + d_row(r, lane);
+        zv[r] = buf_ld1(rz, jok ? (unsigned)((rr * ldz + col) * 4) : kOOB);    // 0 when absent
+        av[r] = buf_ld1(ra, jok ? (unsigned)((rr * ldadd + col) * 4) : kOOB);  // 0 when absent
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = wm * 64 + i * 32 + d_row(r, lane);
+        float v = acc[i][j][r];
+        if (EPI == EPI_DX) {
+          if (silu) {  // block-uniform
+            v *= has_z ? gcl::dsilu_f(zv[r]) : 1.f;
+          } else {
+            const bool neg = has_z && (zv[r] <= 0.f);
+            slope_acc += neg ? (double)(v * zv[r]) : 0.0;
+            v = neg ? v * slope : v;
+          }
+        } else {
+          v += bj;
+        }
+        v += av[r];
+        buf_st1(ry, jok ? (unsigned)((rr * ldy + col) * 4) : kOOB, v);
+      }
+    }
+  }
+  if (EPI == EPI_DX && slope_part) {
+    for (int off = 32; off > 0; off >>= 1) slope_acc += __shfl_down(slope_acc, off, 64);
+    double* dred = reinterpret_cast<double*>(smem);  // all fragment reads ended at the last barrier
+    if (lane == 0) dred[wave] = slope_acc;
+    __syncthreads();
+    if (tid == 0) slope_part[blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
+  }
+}
+
+struct GtGeom {
+  int nt;
+  int64_t total;
+  int per_xcd;
+  unsigned grid;
+};
+static inline GtGeom gt_geom(int64_t rows, int N) {
+  GtGeom g;
+  g.nt = (N + kGtTN - 1) / kGtTN;
+  g.total = gcl::cdiv(rows, kGtTM) * g.nt;
+  // whole row tiles per XCD so that the column tiles of a row tile share an L2
+  const int64_t row_tiles_per_xcd = gcl::cdiv(gcl::cdiv(rows, kGtTM), gcl::kNumXCD);
+  g.per_xcd = (int)(row_tiles_per_xcd * g.nt);
+  g.grid = (unsigned)(g.per_xcd * gcl::kNumXCD);
+  return g;
+}

@@ -58,6 +58,8 @@ __device__ __forceinline__ int64_t win_bytes(int64_t nrows, int64_t ld, int F) {
   return nrows > 0 ? ((nrows - 1) * ld + F) * 4 : 0;
 }
 
+#include "gemm_tile.h"
+
 // ---------------------------------------------------------------------------------------------
 // Y[r, j] = sum_k act(X[r,k]) * Wl[j,k]   with Wl[j,k] = TRANS ? W[k*ldw + j] : W[j*ldw + k]
 //   EPI_BIAS: + bias[j]
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel
                                                           int64_t ldy, int64_t rows, int32_t K, int32_t N,
                                                           const float* __restrict__ Z, int64_t ldz,
                                                           const float* __restrict__ z_slope,
-                                                          double* __restrict__ slope_part) {
+                                                          double* __restrict__ slope_part, int32_t akind) {
   extern __shared__ __align__(16) float smem[];
   const int KE = (K + 3) & ~3;        // K padded to a multiple of 4 (two MFMA k-steps per 8-B read)
   const int KP = KE + 2;              // even stride with KP/2 odd: conflict-free ds_read_b64 fragments
@@ -100,8 +102,10 @@ __global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel
     if (j < N && k < K) v = trans ? W[(int64_t)k * ldw + j] : W[(int64_t)j * ldw + k];
     Wl[j * KP + k] = v;
   }
+  // akind: activation of X (EPI_BIAS) or of Z (EPI_DX); PReLU reads its slope from in_slope / z_slope
   const float slope = in_slope ? *in_slope : 1.f;
-  const bool act = in_slope != nullptr;
+  const bool act = EPI == EPI_BIAS && akind != gcl::kActNone;
+  const bool silu = akind == gcl::kActSilu;
   float* Xw = Xl + (size_t)wave * 32 * KP;
   const int64_t ntiles = (rows + TM - 1) / TM;
   double slope_acc = 0.0;  // fp64: the slope gradient is a long signed sum with heavy cancellation
@@ -145,14 +149,14 @@ __global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel
           float2* d = reinterpret_cast<float2*>(Xw + r * KP + c * 4);
           float v0 = pre[4 * it], v1 = pre[4 * it + 1], v2 = pre[4 * it + 2], v3 = pre[4 * it + 3];
           if (act) {
-            v0 = gcl::prelu_f(v0, slope); v1 = gcl::prelu_f(v1, slope);
-            v2 = gcl::prelu_f(v2, slope); v3 = gcl::prelu_f(v3, slope);
+            v0 = gcl::act_f(v0, slope, akind); v1 = gcl::act_f(v1, slope, akind);
+            v2 = gcl::act_f(v2, slope, akind); v3 = gcl::act_f(v3, slope, akind);
           }
           d[0] = make_float2(v0, v1);
           d[1] = make_float2(v2, v3);
         }
       } else {
-        if (c < KE) Xw[r * KP + c] = act ? gcl::prelu_f(pre[it], slope) : pre[it];  // zero beyond K
+        if (c < KE) Xw[r * KP + c] = act ? gcl::act_f(pre[it], slope, akind) : pre[it];  // zero beyond K
       }
     }
   };
@@ -241,9 +245,13 @@ __global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel
         for (int r = 0; r < 16; ++r) {
           const int rr = wave * 32 + d_row(r, lane);
           float v = acc[s][r];
-          const bool neg = has_z && (zv[r] <= 0.f);
-          slope_acc += neg ? (double)(v * zv[r]) : 0.0;
-          v = neg ? v * zs : v;
+          if (silu) {  // block-uniform
+            v *= has_z ? gcl::dsilu_f(zv[r]) : 1.f;
+          } else {
+            const bool neg = has_z && (zv[r] <= 0.f);
+            slope_acc += neg ? (double)(v * zv[r]) : 0.0;
+            v = neg ? v * zs : v;
+          }
           buf_st1(ry, jok ? (unsigned)((rr * ldy + j) * 4) : kOOB, v);
         }
       } else {
@@ -279,10 +287,10 @@ __global__ __launch_bounds__(256) void linear_valu_kernel(const float* __restric
                                                           int64_t ldy, int64_t rows, int32_t K, int32_t N,
                                                           const float* __restrict__ Z, int64_t ldz,
                                                           const float* __restrict__ z_slope,
-                                                          double* __restrict__ slope_part) {
+                                                          double* __restrict__ slope_part, int32_t akind) {
   __shared__ double red[4];
   const float slope = in_slope ? *in_slope : 1.f;
-  const bool act = in_slope != nullptr;
+  const bool act = EPI == EPI_BIAS && akind != gcl::kActNone;
   const float zs = (EPI == EPI_DX && z_slope) ? *z_slope : 1.f;
   double slope_acc = 0.0;
   const int64_t total = rows * N;
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(256) void linear_valu_kernel(const float* __restric
     float acc = 0.f;
     for (int k = 0; k < K; ++k) {
       float xv = X[r * ldx + k];
-      if (act) xv = gcl::prelu_f(xv, slope);
+      if (act) xv = gcl::act_f(xv, slope, akind);
       const float wv = trans ? W[(int64_t)k * ldw + j] : W[(int64_t)j * ldw + k];
       acc = fmaf(xv, wv, acc);
     }
@@ -300,7 +308,9 @@ __global__ __launch_bounds__(256) void linear_valu_kernel(const float* __restric
       if (bias) acc += bias[j];
     } else if (Z) {
       const float z = Z[r * ldz + j];
-      if (z <= 0.f) {
+      if (akind == gcl::kActSilu) {
+        acc *= gcl::dsilu_f(z);
+      } else if (z <= 0.f) {
         slope_acc += (double)(acc * z);
         acc *= zs;
       }
@@ -342,7 +352,7 @@ template <int NO, int NC, bool VEC>
 __global__ __launch_bounds__(256, (DwCfg<NO, NC>::min_waves)) void dw_mfma_kernel(
     const float* __restrict__ dY, int64_t lddy, const float* __restrict__ X, int64_t ldx,
     const float* __restrict__ in_slope, float* __restrict__ part, float* __restrict__ dbpart, int64_t rows,
-    int32_t Fin, int32_t Fout, int64_t rows_per_block) {
+    int32_t Fin, int32_t Fout, int64_t rows_per_block, int32_t akind) {
   using Cfg = DwCfg<NO, NC>;
   constexpr int WO = Cfg::WO, WC = Cfg::WC, TO = Cfg::TO, TC = Cfg::TC, PRE = Cfg::PRE;
   constexpr int FoutP = Cfg::FoutP, FinP = Cfg::FinP;
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(256, (DwCfg<NO, NC>::min_waves)) void dw_mfma_kerne
   const int li = lane & 31, lk = lane >> 5;
   const int wo = wave % WO, wc = wave / WO;
   const float slope = in_slope ? *in_slope : 1.f;
-  const bool act = in_slope != nullptr;
+  const bool act = akind != gcl::kActNone;
   const int64_t rb = (int64_t)blockIdx.x * rows_per_block;
   const int64_t re = min(rows, rb + rows_per_block);
   const int nrows = (int)(re - rb);
@@ -408,8 +418,8 @@ __global__ __launch_bounds__(256, (DwCfg<NO, NC>::min_waves)) void dw_mfma_kerne
         *reinterpret_cast<float4*>(Yl + r * FoutP + (cg + 8 * j) * 4) = v;
       } else {
         if (act) {
-          v.x = gcl::prelu_f(v.x, slope); v.y = gcl::prelu_f(v.y, slope);
-          v.z = gcl::prelu_f(v.z, slope); v.w = gcl::prelu_f(v.w, slope);
+          v.x = gcl::act_f(v.x, slope, akind); v.y = gcl::act_f(v.y, slope, akind);
+          v.z = gcl::act_f(v.z, slope, akind); v.w = gcl::act_f(v.w, slope, akind);
         }
         *reinterpret_cast<float4*>(Xl + r * FinP + (cg + 8 * (j - NO)) * 4) = v;
       }
@@ -994,7 +1004,7 @@ int lin_geom(int64_t rows, int K, int N, bool vec_x, LinGeom* g) {
 template <int EPI>
 int launch_linear(const float* X, int64_t ldx, const float* in_slope, const float* W, int ldw, int trans,
                   const float* bias, float* Y, int64_t ldy, int64_t rows, int K, int N, const float* Z, int64_t ldz,
-                  const float* z_slope, double* slope_part, int* nparts, hipStream_t st) {
+                  const float* z_slope, double* slope_part, int* nparts, hipStream_t st, int akind) {
   if (rows == 0) {
     if (nparts) *nparts = 0;
     return GCL_OK;
@@ -1003,7 +1013,7 @@ int launch_linear(const float* X, int64_t ldx, const float* in_slope, const floa
     const int64_t total = rows * N;
     int grid = (int)(gcl::cdiv(total, 256) < 4096 ? gcl::cdiv(total, 256) : 4096);
     hipLaunchKernelGGL((linear_valu_kernel<EPI>), dim3(grid), dim3(256), 0, st, X, ldx, in_slope, W, ldw, trans,
-                       bias, Y, ldy, rows, K, N, Z, ldz, z_slope, slope_part);
+                       bias, Y, ldy, rows, K, N, Z, ldz, z_slope, slope_part, akind);
     GCL_CHECK_LAUNCH();
     if (nparts) *nparts = grid;
     return GCL_OK;
@@ -1018,7 +1028,7 @@ int launch_linear(const float* X, int64_t ldx, const float* in_slope, const floa
     { static bool lds_set = false;                                                                          \
       if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
     hipLaunchKernelGGL(kern, dim3(g.grid), dim3(g.waves * 64), g.lds, st, X, ldx, in_slope, W, ldw, trans, bias,  \
-                       Y, ldy, rows, K, N, Z, ldz, z_slope, slope_part);                                          \
+                       Y, ldy, rows, K, N, Z, ldz, z_slope, slope_part, akind);                                   \
   } while (0)
 #define GCL_LIN2(NS_, KT_)                 \
   do {                                     \
@@ -1045,64 +1055,147 @@ int launch_linear(const float* X, int64_t ldx, const float* in_slope, const floa
   return GCL_OK;
 }
 
+// does the resident-panel kernel take this shape?
+// K: contraction length, N: output width.  Measured on MI355X (tools/gemm_bench.py): the 128x128
+// tile kernel wins once the contraction is long or the output fills its 128 columns.
+bool panel_fits(int K, int N, bool vec_x, bool trans) {
+  static const int impl = [] {
+    const char* e = getenv("GCL_DENSE_IMPL");
+    return !e ? 0 : strcmp(e, "tile") == 0 ? 1 : strcmp(e, "panel") == 0 ? 2 : 0;
+  }();
+  const bool tile_ok = vec_x && K % 4 == 0 && N % 4 == 0;
+  if (impl == 1 && tile_ok) return false;
+  if (impl == 0 && tile_ok && (K > 128 || (N >= 128 && (K >= 128 || trans)))) return false;
+  if (K < 1 || K > 256 || N < 1 || N > 256) return false;
+  if (!vec_x && K > 128) return false;
+  int NS = (N + 31) / 32;
+  if (NS == 3) NS = 4;
+  if (NS > 4) NS = 8;
+  const int KP = ((K + 3) & ~3) + 2;
+  return ((size_t)NS * 32 + 64) * KP * sizeof(float) + 64 <= 160 * 1024;
+}
+
+template <int EPI>
+int launch_gemm(const float* X, int64_t ldx, int akind, const float* slope, const float* W, int64_t ldw, int trans,
+                const float* bias, float* Y, int64_t ldy, int64_t rows, int K, int N, const float* Z, int64_t ldz,
+                const float* add, int64_t ldadd, double* slope_part, int* nparts, hipStream_t st) {
+  if (nparts) *nparts = 0;
+  if (rows == 0) return GCL_OK;
+  GCL_CHECK_ARG((K % 4 == 0) && (ldx % 4 == 0) && gcl::aligned16(X), "dense: wide shapes need K %% 4 == 0 and 16-B aligned rows (K=%d ldx=%lld)", K, (long long)ldx);
+  GCL_CHECK_ARG((ldw % 4 == 0) && gcl::aligned16(W) && (!trans || N % 4 == 0), "dense: wide shapes need a 16-B aligned weight block (ldw=%lld N=%d)", (long long)ldw, N);
+  const GtGeom g = gt_geom(rows, N);
+#define GCL_GT(T_)                                                                                                \
+  do {                                                                                                            \
+    auto kern = gemm_tile_kernel<EPI, T_>;                                                                        \
+    { static bool lds_set = false;                                                                                \
+      if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
+    hipLaunchKernelGGL(kern, dim3(g.grid), dim3(256), kGtLds, st, X, ldx, akind, slope, W, ldw, bias, Y, ldy, rows, \
+                       K, N, Z, ldz, add, ldadd, slope_part, g.nt, g.total, g.per_xcd);                           \
+  } while (0)
+  if (trans) GCL_GT(true);
+  else GCL_GT(false);
+#undef GCL_GT
+  GCL_CHECK_LAUNCH();
+  if (nparts) *nparts = (int)g.grid;
+  return GCL_OK;
+}
+
 }  // namespace
 
 extern "C" size_t gcl_colsum_ws_bytes(int64_t, int32_t);
 extern "C" int gcl_colsum(const float*, int64_t, int64_t, int32_t, float*, int32_t, void*, size_t, gcl_stream_t);
 
+static int check_act(const char* who, int act, const float* slope) {
+  GCL_CHECK_ARG(act == GCL_ACT_NONE || act == GCL_ACT_PRELU || act == GCL_ACT_SILU, "%s: unknown activation %d", who, act);
+  GCL_CHECK_ARG(act != GCL_ACT_PRELU || slope, "%s: GCL_ACT_PRELU needs the slope pointer", who);
+  return GCL_OK;
+}
+
+extern "C" int gcl_dense_fwd(const float* x, int64_t ldx, int32_t act, const float* slope, const float* W, int64_t ldw,
+                             const float* bias, const float* addend, int64_t ldadd, float* y, int64_t ldy,
+                             int64_t rows, int32_t Fin, int32_t Fout, gcl_stream_t stream) {
+  GCL_CHECK_ARG(x && W && y, "dense_fwd: null argument");
+  GCL_CHECK_ARG(rows >= 0 && Fin >= 1 && Fout >= 1 && ldx >= Fin && ldy >= Fout && ldw >= Fin && (!addend || ldadd >= Fout),
+                "dense_fwd: bad shape rows=%lld ldx=%lld ldy=%lld ldw=%lld", (long long)rows, (long long)ldx,
+                (long long)ldy, (long long)ldw);
+  if (int rc = check_act("dense_fwd", act, slope)) return rc;
+  const bool vec_x = (Fin % 4 == 0) && (ldx % 4 == 0) && gcl::aligned16(x);
+  if (!addend && ldw == Fin && (use_valu() || panel_fits(Fin, Fout, vec_x, false)))
+    return launch_linear<EPI_BIAS>(x, ldx, act == GCL_ACT_PRELU ? slope : nullptr, W, Fin, 0, bias, y, ldy, rows, Fin,
+                                   Fout, nullptr, 0, nullptr, nullptr, nullptr, (hipStream_t)stream, act);
+  return launch_gemm<EPI_BIAS>(x, ldx, act, act == GCL_ACT_PRELU ? slope : nullptr, W, ldw, 0, bias, y, ldy, rows, Fin,
+                               Fout, nullptr, 0, addend, ldadd, nullptr, nullptr, (hipStream_t)stream);
+}
+
 extern "C" int gcl_linear_fwd(const float* x, int64_t ldx, const float* in_slope, const float* W, const float* bias,
                               float* y, int64_t ldy, int64_t rows, int32_t Fin, int32_t Fout, gcl_stream_t stream) {
-  GCL_CHECK_ARG(x && W && y, "linear_fwd: null argument");
-  GCL_CHECK_ARG(rows >= 0 && ldx >= Fin && ldy >= Fout, "linear_fwd: bad shape rows=%lld ldx=%lld ldy=%lld",
-                (long long)rows, (long long)ldx, (long long)ldy);
-  return launch_linear<EPI_BIAS>(x, ldx, in_slope, W, Fin, 0, bias, y, ldy, rows, Fin, Fout, nullptr, 0, nullptr,
-                                 nullptr, nullptr, (hipStream_t)stream);
+  return gcl_dense_fwd(x, ldx, in_slope ? GCL_ACT_PRELU : GCL_ACT_NONE, in_slope, W, Fin, bias, nullptr, 0, y, ldy, rows,
+                       Fin, Fout, stream);
+}
+
+// slope partials: one double per block of the dx kernel (the tiled kernel launches a block per tile)
+static size_t slope_parts_cap(int64_t rows, int32_t Fin) {
+  const int64_t g = (int64_t)gt_geom(rows, Fin).grid;
+  return (size_t)(g > 4096 ? g : 4096);
 }
 
 extern "C" size_t gcl_linear_bwd_ws_bytes(int64_t rows, int32_t Fin, int32_t Fout) {
-  const size_t FinP = (size_t)((Fin + 31) / 32) * 32;
+  size_t nc = (size_t)(Fin + 31) / 32;
+  if (nc > 4) nc = 4;  // wider inputs are walked in 128-column chunks
+  const size_t FinP = nc * 32;
   size_t no = (size_t)(Fout + 31) / 32;
   no = no <= 2 ? no : no <= 4 ? 4 : 8;
   const size_t FoutP = no * 32;
   const size_t dw = (size_t)kDwBlocks * FoutP * (FinP + 1) * sizeof(float);
-  const size_t sl = (size_t)4096 * sizeof(double);
-  (void)rows;
+  const size_t sl = slope_parts_cap(rows, Fin) * sizeof(double);
   return dw + sl;
 }
 
-extern "C" int gcl_linear_bwd_dx(const float* dy, int64_t lddy, const float* W, const float* x, int64_t ldx,
-                                 const float* in_slope, float* d_in_slope, float* dx, int64_t lddx, int64_t rows,
-                                 int32_t Fin, int32_t Fout, void* ws, size_t ws_bytes, gcl_stream_t stream) {
-  GCL_CHECK_ARG(dy && W && dx, "linear_bwd_dx: null argument");
-  GCL_CHECK_ARG(lddy >= Fout && lddx >= Fin, "linear_bwd_dx: leading dimension too small");
-  GCL_CHECK_ARG(!in_slope || (x && ldx >= Fin), "linear_bwd_dx: in_slope given without the forward input x");
+extern "C" int gcl_dense_bwd_dx(const float* dy, int64_t lddy, const float* W, int64_t ldw, const float* z, int64_t ldz,
+                                int32_t act, const float* slope, float* d_slope, const float* addend, int64_t ldadd,
+                                float* dx, int64_t lddx, int64_t rows, int32_t Fin, int32_t Fout, void* ws,
+                                size_t ws_bytes, gcl_stream_t stream) {
+  GCL_CHECK_ARG(dy && W && dx, "dense_bwd_dx: null argument");
+  GCL_CHECK_ARG(lddy >= Fout && lddx >= Fin && ldw >= Fin && (!addend || ldadd >= Fin), "dense_bwd_dx: leading dimension too small");
+  if (int rc = check_act("dense_bwd_dx", act, slope)) return rc;
+  GCL_CHECK_ARG(act == GCL_ACT_NONE || (z && ldz >= Fin), "dense_bwd_dx: activation given without its pre-activation z");
   hipStream_t st = (hipStream_t)stream;
+  const float* sl = act == GCL_ACT_PRELU ? slope : nullptr;
   double* slope_part = nullptr;
-  if (in_slope && d_in_slope) {
-    GCL_CHECK_ARG(ws && ws_bytes >= 4096 * sizeof(double) && gcl::aligned16(ws), "linear_bwd_dx: workspace too small");
+  if (sl && d_slope) {
+    GCL_CHECK_ARG(ws && ws_bytes >= slope_parts_cap(rows, Fin) * sizeof(double) && gcl::aligned16(ws), "dense_bwd_dx: workspace too small");
     slope_part = (double*)ws;
   }
-  int nparts = 0;
-  // contraction over Fout: "weights" are W^T, i.e. Wl[j=c][k=o] = W[o*Fin + c]
-  int rc = launch_linear<EPI_DX>(dy, lddy, nullptr, W, Fin, 1, nullptr, dx, lddx, rows, Fout, Fin,
-                                 in_slope ? x : nullptr, ldx, in_slope, slope_part, &nparts, st);
+  int nparts = 0, rc;
+  const float* zz = act == GCL_ACT_NONE ? nullptr : z;
+  const bool vec_x = (Fout % 4 == 0) && (lddy % 4 == 0) && gcl::aligned16(dy);
+  // contraction over Fout: "weights" are W^T, i.e. Wl[j=c][k=o] = W[o*ldw + c]
+  if (!addend && ldw == Fin && (use_valu() || panel_fits(Fout, Fin, vec_x, true)))
+    rc = launch_linear<EPI_DX>(dy, lddy, nullptr, W, Fin, 1, nullptr, dx, lddx, rows, Fout, Fin, zz, ldz, sl, slope_part,
+                               &nparts, st, act);
+  else
+    rc = launch_gemm<EPI_DX>(dy, lddy, act, sl, W, ldw, 1, nullptr, dx, lddx, rows, Fout, Fin, zz, ldz, addend, ldadd,
+                             slope_part, &nparts, st);
   if (rc) return rc;
   if (slope_part && nparts > 0) {
-    hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(64), 0, st, slope_part, nparts, d_in_slope);
+    hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(64), 0, st, slope_part, nparts, d_slope);
     GCL_CHECK_LAUNCH();
   }
   return GCL_OK;
 }
 
-extern "C" int gcl_linear_bwd_dw(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* in_slope,
-                                 float* dW, float* db, int64_t rows, int32_t Fin, int32_t Fout, int32_t accumulate,
-                                 void* ws, size_t ws_bytes, gcl_stream_t stream) {
-  GCL_CHECK_ARG(dy && x && dW, "linear_bwd_dw: null argument");
-  GCL_CHECK_ARG(lddy >= Fout && ldx >= Fin, "linear_bwd_dw: leading dimension too small");
-  GCL_CHECK_ARG(Fin >= 1 && Fin <= 128 && Fout >= 1 && Fout <= 256,
-                "linear_bwd_dw: unsupported Fin=%d Fout=%d (Fin<=128, Fout<=256)", Fin, Fout);
-  GCL_CHECK_ARG(ws && ws_bytes >= gcl_linear_bwd_ws_bytes(rows, Fin, Fout), "linear_bwd_dw: workspace too small");
-  hipStream_t st = (hipStream_t)stream;
+extern "C" int gcl_linear_bwd_dx(const float* dy, int64_t lddy, const float* W, const float* x, int64_t ldx,
+                                 const float* in_slope, float* d_in_slope, float* dx, int64_t lddx, int64_t rows,
+                                 int32_t Fin, int32_t Fout, void* ws, size_t ws_bytes, gcl_stream_t stream) {
+  GCL_CHECK_ARG(!in_slope || (x && ldx >= Fin), "linear_bwd_dx: in_slope given without the forward input x");
+  return gcl_dense_bwd_dx(dy, lddy, W, Fin, in_slope ? x : nullptr, ldx, in_slope ? GCL_ACT_PRELU : GCL_ACT_NONE,
+                          in_slope, d_in_slope, nullptr, 0, dx, lddx, rows, Fin, Fout, ws, ws_bytes, stream);
+}
+
+// one (<=256 x <=128) block of dW
+static int dw_block(const float* dy, int64_t lddy, const float* x, int64_t ldx, int akind, const float* in_slope,
+                    float* dW, int64_t lddw, float* db, int64_t rows, int32_t Fin, int32_t Fout, int32_t accumulate,
+                    void* ws, hipStream_t st) {
   const int NC = (Fin + 31) / 32;
   int NO = (Fout + 31) / 32;
   NO = NO <= 2 ? NO : NO <= 4 ? 4 : 8;  // instantiated: 1, 2, 4, 8 (extra slabs are zero)
@@ -1123,7 +1216,7 @@ extern "C" int gcl_linear_bwd_dw(const float* dy, int64_t lddy, const float* x, 
     { static bool lds_set = false;                                                                          \
       if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, dy, lddy, x, ldx, in_slope, part,          \
-                       db ? dbpart : nullptr, rows, Fin, Fout, rpb);                                              \
+                       db ? dbpart : nullptr, rows, Fin, Fout, rpb, akind);                                       \
   } while (0)
 #define GCL_DW2(NO_, NC_)              \
   do {                                 \
@@ -1149,10 +1242,40 @@ extern "C" int gcl_linear_bwd_dw(const float* dy, int64_t lddy, const float* x, 
 #undef GCL_DW2
 #undef GCL_DW3
   GCL_CHECK_LAUNCH();
-  int rc = gcl::launch_reduce_parts(part, (int)nblk, (int64_t)FoutP * FinP, FinP, dW, Fin, Fout, Fin, accumulate, st);
+  int rc = gcl::launch_reduce_parts(part, (int)nblk, (int64_t)FoutP * FinP, FinP, dW, (int)lddw, Fout, Fin, accumulate, st);
   if (rc) return rc;
   if (db) rc = gcl::launch_reduce_parts(dbpart, (int)nblk, (int64_t)FoutP, FoutP, db, Fout, 1, Fout, accumulate, st);
   return rc;
+}
+
+extern "C" int gcl_dense_bwd_dw(const float* dy, int64_t lddy, const float* x, int64_t ldx, int32_t act,
+                                const float* slope, float* dW, int64_t lddw, float* db, int64_t rows, int32_t Fin,
+                                int32_t Fout, int32_t accumulate, void* ws, size_t ws_bytes, gcl_stream_t stream) {
+  GCL_CHECK_ARG(dy && x && dW, "dense_bwd_dw: null argument");
+  GCL_CHECK_ARG(lddy >= Fout && ldx >= Fin && lddw >= Fin, "dense_bwd_dw: leading dimension too small");
+  GCL_CHECK_ARG(Fin >= 1 && Fout >= 1, "dense_bwd_dw: bad shape");
+  GCL_CHECK_ARG(lddw < (1 << 30), "dense_bwd_dw: lddw too large");
+  if (int rc = check_act("dense_bwd_dw", act, slope)) return rc;
+  GCL_CHECK_ARG(ws && ws_bytes >= gcl_linear_bwd_ws_bytes(rows, Fin, Fout), "dense_bwd_dw: workspace too small");
+  const float* sl = act == GCL_ACT_PRELU ? slope : nullptr;
+  // wide layers: blocks of <= 256 outputs x <= 128 inputs (dY is re-read once per input block)
+  for (int o0 = 0; o0 < Fout; o0 += 256) {
+    const int fo = Fout - o0 < 256 ? Fout - o0 : 256;
+    for (int c0 = 0; c0 < Fin; c0 += 128) {
+      const int fi = Fin - c0 < 128 ? Fin - c0 : 128;
+      int rc = dw_block(dy + o0, lddy, x + c0, ldx, act, sl, dW + (int64_t)o0 * lddw + c0, lddw,
+                        (db && c0 == 0) ? db + o0 : nullptr, rows, fi, fo, accumulate, ws, (hipStream_t)stream);
+      if (rc) return rc;
+    }
+  }
+  return GCL_OK;
+}
+
+extern "C" int gcl_linear_bwd_dw(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* in_slope,
+                                 float* dW, float* db, int64_t rows, int32_t Fin, int32_t Fout, int32_t accumulate,
+                                 void* ws, size_t ws_bytes, gcl_stream_t stream) {
+  return gcl_dense_bwd_dw(dy, lddy, x, ldx, in_slope ? GCL_ACT_PRELU : GCL_ACT_NONE, in_slope, dW, Fin, db, rows, Fin,
+                          Fout, accumulate, ws, ws_bytes, stream);
 }
 
 // Fused path geometry / workspace (see linear_bwd_fused_kernel)

@@ -1,7 +1,7 @@
 """The experiment configurations BASELINE.json names, restated as `ExperimentConfig` objects.
 
 Values are those of the reference's `experiments/{baseline,attention,sparse_attention,
-wb2_512x256_19f_ar}/config.json` (checked against `tests/golden/config_parse.json`, which was
+wb2_512x256_19f_ar,wb2_512x256_19f_ar_v2,region_krsk_cds_19f}/config.json` (checked against `tests/golden/config_parse.json`, which was
 produced by parsing the reference's files with the reference's own pydantic schema)."""
 from .config import ExperimentConfig
 
@@ -20,7 +20,21 @@ def _pipeline(enc_hidden, F, proc_type, proc_hidden, dec_mlp_hidden, dec_mlp_out
     }
 
 
-GRID = {"baseline": (32, 64), "attention": (32, 64), "attention_h4": (32, 64), "sparse_attention": (32, 64),
+def _interaction_pipeline(F, steps, enc_hidden, dec_mlp_hidden, dec_mlp_out, dec_hidden, out_dim, act="swish"):
+    """The InteractionNet family (`experiments/wb2_512x256_19f_ar_v2`, `multires_*`, `region_*`)."""
+    return {
+        "encoder": {"mlp": {"mlp_hidden_dims": enc_hidden, "output_dim": F, "use_layer_norm": True,
+                            "layer_norm_mode": "node"},
+                    "gcn": {"layer_type": "conv_gcn", "hidden_dims": [F, F], "output_dim": F, "activation": act}},
+        "processor": {"gcn": {"layer_type": "interaction_net", "output_dim": F, "activation": act,
+                              "use_layer_norm": True, "num_message_passing_steps": steps, "edge_feature_dim": 4}},
+        "decoder": {"mlp": {"mlp_hidden_dims": dec_mlp_hidden, "output_dim": dec_mlp_out, "use_layer_norm": False},
+                    "gcn": {"layer_type": "conv_gcn", "hidden_dims": dec_hidden, "output_dim": out_dim,
+                            "activation": act}},
+    }
+
+
+GRID = {"wb2_512x256_19f_ar_v2": (256, 512), "region_krsk_cds_19f": (32, 64), "baseline": (32, 64), "attention": (32, 64), "attention_h4": (32, 64), "sparse_attention": (32, 64),
         "wb2_512x256_19f_ar": (256, 512)}
 
 
@@ -41,6 +55,14 @@ def experiment(name: str, mesh_levels=None) -> ExperimentConfig:
     elif name == "wb2_512x256_19f_ar":
         pipe = _pipeline([128, 128], 128, "conv_gcn", [128] * 4, [128, 64], 64, [64, 64], 19)
         graph.update(grid2mesh_radius_query=0.6, mesh_levels=mesh_levels or [4, 6])
+        data.update(num_features_used=19)
+    elif name == "wb2_512x256_19f_ar_v2":  # latent 256, 12 unshared InteractionNet steps, swish
+        pipe = _interaction_pipeline(256, 12, [256, 256], [256, 128], 128, [128, 128], 19)
+        graph.update(grid2mesh_radius_query=0.6, mesh_levels=mesh_levels or [4, 6])
+        data.update(num_features_used=19)
+    elif name == "region_krsk_cds_19f":  # latent 128, 8 steps (its regional grid is replaced by GRID's)
+        pipe = _interaction_pipeline(128, 8, [128, 128], [128, 64], 64, [64, 64], 19)
+        graph.update(grid2mesh_radius_query=0.6, mesh_levels=mesh_levels or [3, 5])
         data.update(num_features_used=19)
     else:
         raise KeyError(name)

@@ -122,18 +122,23 @@ class GCNStackFn(torch.autograd.Function):
         x3 = _flat3(x.detach())
         B, n, _ = x3.shape
         slope_p = params[2 * L]
+        # activation between the convs: learnable PReLU slope (params[2L]), SiLU, or ReLU as a PReLU
+        # with the owner's constant zero slope (src/models.py:154-163, :316)
+        akind = getattr(owner, "act_kind", hip.ACT_PRELU)
+        slope_t = slope_p.detach() if slope_p is not None else getattr(owner, "const_slope", None)
         ps = []  # pre-activation outputs of every conv
-        cur, slope = x3, None
+        cur = x3
         for k in range(L):
             W, b = params[2 * k].detach(), params[2 * k + 1].detach()
             Fout = W.shape[0]
             ldh = (Fout + 3) // 4 * 4  # padded scratch so the gather can use 16-B loads
-            h = hip.linear_fwd(cur.view(B * n, -1), W, None, slope, ld_out=ldh)
+            h = hip.linear_fwd(cur.view(B * n, -1), W, None, slope_t if k > 0 else None, ld_out=ldh,
+                               act=akind if k > 0 else hip.ACT_NONE)
             h3 = torch.as_strided(h, (B, n, Fout), (n * ldh, ldh, 1))
             p = hip.aggregate(graph, h3, b)
             ps.append(p)
             cur = p
-            slope = slope_p.detach() if slope_p is not None else None
+        ctx.akind, ctx.slope_t = akind, slope_t
         out, stats = cur, None
         if has_ln:
             o2, stats = hip.layernorm_fwd(cur.view(B * n, -1), params[-2].detach(), params[-1].detach(), eps)
@@ -160,7 +165,7 @@ class GCNStackFn(torch.autograd.Function):
             dp = dy3
         si = 2 * L
         dsl = G.dst[si] if params[si] is not None else None
-        slope_t = params[si].detach() if params[si] is not None else None
+        slope_t, akind = ctx.slope_t, ctx.akind
         dx = None
         if G.dst[2 * L - 1] is not None:  # bias of the last conv: its dp comes from outside this stack
             hip.colsum(dp.reshape(B * n, -1), G.dst[2 * L - 1], G.acc[2 * L - 1])
@@ -173,7 +178,8 @@ class GCNStackFn(torch.autograd.Function):
             if k > 0:
                 # one fused launch: dp_{k-1} (with PReLU'), dW_k, d(slope) and the bias gradient of
                 # conv k-1 (= column sums of dp_{k-1})
-                dp = hip.linear_bwd_all(dh2, W, inp, slope_t, dsl, dW, None, G.dst[2 * k - 1], G.acc[wi]).view(B, n, -1)
+                dp = hip.linear_bwd_all(dh2, W, inp, slope_t, dsl, dW, None, G.dst[2 * k - 1], G.acc[wi],
+                                        act=akind).view(B, n, -1)
             else:
                 hip.linear_bwd_dw(dh2, inp, None, dW, None, G.acc[wi])
                 if ctx.needs_input_grad[0]:
@@ -197,7 +203,9 @@ class GATLayerFn(torch.autograd.Function):
         B, n, _ = x3.shape
         Cc = W.shape[0] // H
         sl = slope.detach() if slope is not None else None
-        h = hip.linear_fwd(x3.view(B * n, -1), W.detach(), None, sl).view(B, n, H * Cc)
+        act = getattr(owner, "_in_act", None)  # None: PReLU when a slope is given
+        h = hip.linear_fwd(x3.view(B * n, -1), W.detach(), None, sl, act=act).view(B, n, H * Cc)
+        ctx.act = act
         y, a_s, a_d, alpha = hip.gat_fwd(graph, h, att_src.detach().reshape(-1), att_dst.detach().reshape(-1),
                                          bias.detach(), H, Cc)
         alpha_edges = hip.gat_alpha_edge_order(graph, alpha[0], H) if want_alpha else torch.empty(0, device=x3.device)
@@ -234,10 +242,10 @@ class GATLayerFn(torch.autograd.Function):
         inp = ctx.x3.view(B * n, -1)
         sl = slope.detach() if slope is not None else None
         if G.dst[1] is not None:
-            hip.linear_bwd_dw(dh2, inp, sl, G.dst[1], None, G.acc[1])
+            hip.linear_bwd_dw(dh2, inp, sl, G.dst[1], None, G.acc[1], act=ctx.act)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = hip.linear_bwd_dx(dh2, W.detach(), inp if sl is not None else None, sl, G.dst[0] if sl is not None else None)
+            dx = hip.linear_bwd_dx(dh2, W.detach(), inp, sl, G.dst[0] if sl is not None else None, act=ctx.act)
             dx = dx.view(B, n, -1)
             if ctx.squeeze:
                 dx = dx[0]
@@ -364,3 +372,156 @@ class Gather2Fn(torch.autograd.Function):
             bc = ctx.sb[0] == 1 and ctx.B > 1
             db = hip.gather2_rows(g, inv_b, None, None, ctx.sb[1], ctx.B, sum_batch=bc)
         return da, db, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# InteractionNet processor (src/models.py:166-285): edge encoder + N unshared message-passing steps.
+# The first edge-MLP layer on cat([x_s, x_r, e]) is split by operand,
+#     hidden = e We^T + (x Ws^T)[senders] + (x Wr^T)[receivers] + b,     [Ws | Wr | We] = edge_mlp[0].weight
+# so the per-edge contraction is D wide instead of 3D and the node projections are done once per
+# node; same for cat([x, agg]) of the node MLP.  Edges are kept receiver-sorted internally
+# (EdgeLayout): the scatter-mean is then a contiguous segment mean and nothing needs atomics.
+# params layout: [enc_W, enc_b, slope_enc] + per step [We1, be1, We2, be2, Wn1, bn1, Wn2, bn2, slope,
+#                 gamma_e, beta_e, gamma_n, beta_n]   (slope* only for PReLU, gamma/beta only with LN; None otherwise)
+# ------------------------------------------------------------------------------------------------
+class EdgeLayout:
+    """Receiver-sorted view of a reference-layout edge_index [2, E] (+ its sender-sorted transpose)."""
+
+    def __init__(self, edge_index: torch.Tensor, n: int, device):
+        ei = edge_index.detach().to("cpu", torch.int64)
+        snd, rcv = ei[0], ei[1]
+        if ei.numel() and (int(ei.min()) < 0 or int(ei.max()) >= n):
+            raise ValueError("edge_index refers to nodes outside [0, n)")
+        order = torch.sort(rcv, stable=True).indices            # sorted position -> reference edge id
+        self.order = order.to(device)
+        snd_s, rcv_s = snd[order], rcv[order]
+        cnt = torch.bincount(rcv_s, minlength=n)
+        rowptr = torch.zeros(n + 1, dtype=torch.int64)
+        rowptr[1:] = torch.cumsum(cnt, 0)
+        torder = torch.sort(snd_s, stable=True).indices        # sender-grouped list of sorted positions
+        tcnt = torch.bincount(snd_s, minlength=n)
+        trowptr = torch.zeros(n + 1, dtype=torch.int64)
+        trowptr[1:] = torch.cumsum(tcnt, 0)
+        i32 = lambda t: t.to(torch.int32).to(device)
+        self.n, self.E = n, int(ei.shape[1])
+        self.snd, self.rcv, self.rowptr = i32(snd_s), i32(rcv_s), i32(rowptr)
+        self.tperm, self.trowptr = i32(torder), i32(trowptr)
+        self.invdeg = (1.0 / cnt.clamp(min=1).to(torch.float32)).to(device)
+
+
+class InteractionNetFn(torch.autograd.Function):
+    PER_STEP = 13
+
+    @staticmethod
+    def forward(ctx, x, owner, lay: EdgeLayout, raw_edges, n_steps: int, act: int, use_ln: bool, eps: float, *params):
+        squeeze = x.dim() == 2
+        x3 = _flat3(x.detach())
+        B, n, D = x3.shape
+        E = lay.E
+        P = [p.detach() if p is not None else None for p in params]
+        slope_enc = P[2]
+        e0pre = hip.dense_fwd(raw_edges, P[0], P[1])                       # [E, D]  batch-invariant
+        e0 = hip.act_fwd(e0pre, act, slope_enc)
+        e = e0.unsqueeze(0) if B == 1 else e0.unsqueeze(0).expand(B, E, D).contiguous()
+        saved = []
+        xc = x3
+        for k in range(n_steps):
+            We1, be1, We2, be2, Wn1, bn1, Wn2, bn2, slope, ge, bte, gn, btn = P[3 + 13 * k: 16 + 13 * k]
+            last = k == n_steps - 1
+            x2, e2 = xc.view(B * n, D), e.view(B * E, D)
+            # edge update
+            PS = torch.empty(B, n, 2 * D, dtype=torch.float32, device=x3.device)
+            PS2 = PS.view(B * n, 2 * D)
+            hip.dense_fwd(x2, We1[:, :D], None, out=PS2[:, :D])
+            hip.dense_fwd(x2, We1[:, D:2 * D], None, out=PS2[:, D:])
+            H = hip.dense_fwd(e2, We1[:, 2 * D:], be1).view(B, E, D)
+            hip.edge_combine(H, None, PS[:, :, :D], lay.snd, None, PS[:, :, D:], lay.rcv, out3=H)
+            U = hip.dense_fwd(H.view(B * E, D), We2, be2, act, slope).view(B, E, D)
+            agg = hip.segment_reduce(U, None, lay.rowptr, True)
+            epre = estats = None
+            if not last:  # the edge state after the last step is never read (src/models.py:282-285)
+                epre = hip.edge_combine(e, U, None, None, None, None, None, out3=U)  # e + U, in place of U
+                if use_ln:
+                    e_next, estats = hip.graphnorm_fwd(epre, ge, bte, eps)
+                else:
+                    e_next = epre
+            # node update
+            Hn = hip.dense_fwd(x2, Wn1[:, :D], bn1)
+            hip.dense_fwd(agg.view(B * n, D), Wn1[:, D:], None, addend=Hn, out=Hn)
+            xpre = hip.dense_fwd(Hn, Wn2, bn2, act, slope, addend=x2)
+            xstats = None
+            if use_ln:
+                xn, xstats = hip.layernorm_fwd(xpre, gn, btn, eps)
+            else:
+                xn = xpre
+            saved.append((xc, e, H, agg, epre, estats, Hn, xpre, xstats))
+            xc = xn.view(B, n, D)
+            if not last:
+                e = e_next
+        ctx.owner, ctx.lay, ctx.raw, ctx.n_steps, ctx.act, ctx.use_ln, ctx.eps = owner, lay, raw_edges, n_steps, act, use_ln, eps
+        ctx.params, ctx.saved, ctx.e0pre, ctx.squeeze, ctx.dims = params, saved, e0pre, squeeze, (B, n, D, E)
+        return xc[0] if squeeze else xc
+
+    @staticmethod
+    def backward(ctx, dy):
+        params, lay, act, use_ln, eps = ctx.params, ctx.lay, ctx.act, ctx.use_ln, ctx.eps
+        B, n, D, E = ctx.dims
+        needs = list(ctx.needs_input_grad[8:])
+        G = _Grads(list(params), needs)
+        P = [p.detach() if p is not None else None for p in params]
+
+        def dst(i):  # gradient destination of parameter i (a scratch tensor when not wanted)
+            return G.dst[i] if G.dst[i] is not None else (torch.zeros_like(P[i]) if P[i] is not None else None)
+
+        dx = _flat3(dy).view(B * n, D)
+        de = None  # gradient wrt the edge state flowing into the step above
+        for k in range(ctx.n_steps - 1, -1, -1):
+            o = 3 + 13 * k
+            We1, be1, We2, be2, Wn1, bn1, Wn2, bn2, slope, ge, bte, gn, btn = P[o: o + 13]
+            xc, e, H, agg, epre, estats, Hn, xpre, xstats = ctx.saved[k]
+            ctx.saved[k] = None
+            x2, e2, H2 = xc.view(B * n, D), e.view(B * E, D), H.view(B * E, D)
+            dsl = dst(o + 8)
+            # node side
+            if use_ln:
+                dxpre = hip.layernorm_bwd(dx, xpre, gn, xstats, dst(o + 11), dst(o + 12), G.acc[o + 11] and G.acc[o + 12])
+            else:
+                dxpre = dx
+            dHn = hip.dense_bwd_dx(dxpre, Wn2, Hn, act, slope, dsl)
+            hip.dense_bwd_dw(dxpre, Hn, dst(o + 6), dst(o + 7), G.acc[o + 6], act, slope)
+            dxa = hip.dense_bwd_dx(dHn, Wn1[:, :D], addend=dxpre)
+            dagg = hip.dense_bwd_dx(dHn, Wn1[:, D:])
+            dWn1 = dst(o + 4)
+            hip.dense_bwd_dw(dHn, x2, dWn1[:, :D], dst(o + 5), G.acc[o + 4])
+            hip.dense_bwd_dw(dHn, agg.view(B * n, D), dWn1[:, D:], None, G.acc[o + 4])
+            # edge side
+            depre = None
+            if de is not None:
+                depre = hip.graphnorm_bwd(de, epre, ge, estats, dst(o + 9), dst(o + 10), G.acc[o + 9] and G.acc[o + 10],
+                                          eps) if use_ln else de
+            dU = hip.edge_combine(depre, None, dagg.view(B, n, D), lay.rcv, lay.invdeg, None, None)
+            dU2 = dU.view(B * E, D)
+            dH = hip.dense_bwd_dx(dU2, We2, H2, act, slope, dsl)
+            hip.dense_bwd_dw(dU2, H2, dst(o + 2), dst(o + 3), G.acc[o + 2], act, slope)
+            dWe1 = dst(o)
+            de_in = hip.dense_bwd_dx(dH, We1[:, 2 * D:], addend=depre.view(B * E, D) if depre is not None else None)
+            hip.dense_bwd_dw(dH, e2, dWe1[:, 2 * D:], dst(o + 1), G.acc[o])
+            dPS = torch.empty(B, n, 2 * D, dtype=torch.float32, device=dH.device)
+            dH3 = dH.view(B, E, D)
+            hip.segment_reduce(dH3, lay.tperm, lay.trowptr, False, out3=dPS[:, :, :D])
+            hip.segment_reduce(dH3, None, lay.rowptr, False, out3=dPS[:, :, D:])
+            dPS2 = dPS.view(B * n, 2 * D)
+            t = hip.dense_bwd_dx(dPS2[:, :D], We1[:, :D], addend=dxa)
+            dx = hip.dense_bwd_dx(dPS2[:, D:], We1[:, D:2 * D], addend=t, out=t)
+            hip.dense_bwd_dw(dPS2[:, :D], x2, dWe1[:, :D], None, G.acc[o])
+            hip.dense_bwd_dw(dPS2[:, D:], x2, dWe1[:, D:2 * D], None, G.acc[o])
+            de = de_in.view(B, E, D)
+        # edge encoder (batch-invariant: its gradient is the sum over samples)
+        de0 = de[0] if B == 1 else de.sum(dim=0)
+        de0pre = hip.act_bwd(ctx.e0pre, de0.contiguous(), act, P[2], dst(2))
+        hip.dense_bwd_dw(de0pre, ctx.raw, dst(0), dst(1), G.acc[0])
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = dx.view(B, n, D)
+            gx = gx[0] if ctx.squeeze else gx
+        return (gx, None, None, None, None, None, None, None) + G.out()

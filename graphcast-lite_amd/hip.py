@@ -63,6 +63,16 @@ _SIGNATURES = {
     "gcl_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     "gcl_adam_step_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _vp]),
     "gcl_copy_rows": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "gcl_dense_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "gcl_dense_bwd_dx": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32,
+                                   _vp, C.c_size_t, _vp]),
+    "gcl_dense_bwd_dw": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp,
+                                   C.c_size_t, _vp]),
+    "gcl_segment_reduce": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "gcl_edge_combine": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i32, _i64, _i32, _vp]),
+    "gcl_act_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "gcl_act_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "gcl_act_bwd_ws_bytes": (C.c_size_t, []),
     "gcl_ar_advance": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32,
                                  _i32, _vp]),
     "gcl_gather2_rows": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
@@ -206,35 +216,71 @@ def _ld(t: torch.Tensor) -> int:
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
-def linear_fwd(x, W, bias, in_slope, out=None, ld_out=None):
+def _act_of(act, slope):
+    return (ACT_PRELU if slope is not None else ACT_NONE) if act is None else int(act)
+
+
+def linear_fwd(x, W, bias, in_slope, out=None, ld_out=None, act=None):
+    """y = act(x) W^T + bias; act None: PReLU when in_slope is given, else identity."""
     rows, Fin = x.shape
     Fout = W.shape[0]
     if out is None:
         ld = ld_out or Fout
         out = torch.empty(rows, ld, dtype=torch.float32, device=x.device)[:, :Fout]
-    _check(lib().gcl_linear_fwd(_p(x), _ld(x), _p(in_slope), _p(W), _p(bias), _p(out), _ld(out), rows, Fin, Fout, _stream()))
+    _check(lib().gcl_dense_fwd(_p(x), _ld(x), _act_of(act, in_slope), _p(in_slope), _p(W), W.stride(0), _p(bias), None, 0,
+                               _p(out), _ld(out), rows, Fin, Fout, _stream()))
     return out
 
 
-def linear_bwd_dx(dy, W, x, in_slope, d_in_slope):
+def linear_bwd_dx(dy, W, x, in_slope, d_in_slope, act=None):
+    a = _act_of(act, in_slope)
+    return dense_bwd_dx(dy, W, x if a != ACT_NONE else None, a, in_slope, d_in_slope)
+
+
+def linear_bwd_dw(dy, x, in_slope, dW, db, accumulate: bool, act=None):
+    dense_bwd_dw(dy, x, dW, db, accumulate, _act_of(act, in_slope), in_slope)
+
+
+ACT_NONE, ACT_PRELU, ACT_SILU = 0, 1, 2
+
+
+def dense_fwd(x, W, bias, act=ACT_NONE, slope=None, addend=None, out=None):
+    """y = act(x) W^T + bias + addend.  x / W / addend / out may be column blocks (unit channel
+    stride, any row stride) of wider tensors."""
+    rows, Fin = x.shape
+    Fout = W.shape[0]
+    assert W.shape[1] == Fin and W.stride(1) == 1 and x.stride(1) == 1
+    if out is None:
+        out = torch.empty(rows, Fout, dtype=torch.float32, device=x.device)
+    _check(lib().gcl_dense_fwd(_p(x), _ld(x), int(act), _p(slope), _p(W), W.stride(0), _p(bias), _p(addend),
+                               _ld(addend) if addend is not None else 0, _p(out), _ld(out), rows, Fin, Fout, _stream()))
+    return out
+
+
+def dense_bwd_dx(dy, W, z=None, act=ACT_NONE, slope=None, d_slope=None, addend=None, out=None):
+    """dx = (dy W) * act'(z) + addend."""
     rows, Fout = dy.shape
     Fin = W.shape[1]
-    dx = torch.empty(rows, Fin, dtype=torch.float32, device=dy.device)
+    assert W.shape[0] == Fout and W.stride(1) == 1
+    if out is None:
+        out = torch.empty(rows, Fin, dtype=torch.float32, device=dy.device)
     nb = lib().gcl_linear_bwd_ws_bytes(rows, Fin, Fout)
     ws = workspace(nb, dy.device)
-    _check(lib().gcl_linear_bwd_dx(
-        _p(dy), _ld(dy), _p(W), _p(x) if in_slope is not None else None, _ld(x) if in_slope is not None else 0,
-        _p(in_slope), _p(d_in_slope), _p(dx), Fin, rows, Fin, Fout, ws.data_ptr(), ws.numel(), _stream()))
-    return dx
+    _check(lib().gcl_dense_bwd_dx(_p(dy), _ld(dy), _p(W), W.stride(0), _p(z), _ld(z) if z is not None else 0, int(act),
+                                  _p(slope), _p(d_slope), _p(addend), _ld(addend) if addend is not None else 0, _p(out),
+                                  _ld(out), rows, Fin, Fout, ws.data_ptr(), ws.numel(), _stream()))
+    return out
 
 
-def linear_bwd_dw(dy, x, in_slope, dW, db, accumulate: bool):
+def dense_bwd_dw(dy, x, dW, db, accumulate: bool, act=ACT_NONE, slope=None):
+    """dW (+)= dy^T act(x) (dW may be a column block of a wider gradient), db (+)= colsum(dy)."""
     rows, Fout = dy.shape
     Fin = x.shape[1]
+    assert tuple(dW.shape) == (Fout, Fin) and dW.stride(1) == 1
     nb = lib().gcl_linear_bwd_ws_bytes(rows, Fin, Fout)
     ws = workspace(nb, dy.device)
-    _check(lib().gcl_linear_bwd_dw(_p(dy), _ld(dy), _p(x), _ld(x), _p(in_slope), _p(dW), _p(db), rows, Fin, Fout,
-                                   1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()))
+    _check(lib().gcl_dense_bwd_dw(_p(dy), _ld(dy), _p(x), _ld(x), int(act), _p(slope), _p(dW), dW.stride(0), _p(db), rows,
+                                  Fin, Fout, 1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()))
 
 
 # bench.py sets this to {"graph": Graph, "events": []} to time the forward aggregation launches of
@@ -242,8 +288,15 @@ def linear_bwd_dw(dy, x, in_slope, dW, db, accumulate: bool):
 AGG_PROFILE = None
 
 
-def linear_bwd_all(dy, W, x, in_slope, d_in_slope, dW, db, colsum_dx, accumulate: bool):
+def linear_bwd_all(dy, W, x, in_slope, d_in_slope, dW, db, colsum_dx, accumulate: bool, act=None):
     """dx (pre-activation gradient) + dW (+ db, slope gradient, column sums of dx) in one call."""
+    a = _act_of(act, in_slope)
+    if a == ACT_SILU:  # the fused kernel knows PReLU only
+        dense_bwd_dw(dy, x, dW, db, accumulate, a, None)
+        dx = dense_bwd_dx(dy, W, x, a, None, None)
+        if colsum_dx is not None:
+            colsum(dx, colsum_dx, accumulate)
+        return dx
     rows, Fout = dy.shape
     Fin = W.shape[1]
     dx = torch.empty(rows, Fin, dtype=torch.float32, device=dy.device)
@@ -437,3 +490,51 @@ def ar_advance(state4, delta3, y_step3, chan_kind, out3, out_off: int, residual:
         out3.stride(1) if out3 is not None else 0, out3.stride(0) if out3 is not None else 0, int(out_off), B, G, obs, Cc,
         1 if residual else 0, _stream()))
     return new_state
+
+
+def segment_reduce(src3, perm, rowptr, mean: bool, out3=None):
+    """src3 [B, E, D] (unit channel stride) -> out3 [B, n, D]: per-segment sum / mean of rows
+    perm[rowptr[i]:rowptr[i+1]] (perm None: the rows themselves)."""
+    B, _, D = src3.shape
+    n = rowptr.numel() - 1
+    if out3 is None:
+        out3 = torch.empty(B, n, D, dtype=torch.float32, device=src3.device)
+    assert src3.stride(2) == 1 and out3.stride(2) == 1 and tuple(out3.shape) == (B, n, D)
+    _check(lib().gcl_segment_reduce(_p(src3), src3.stride(1), src3.stride(0), _pi(perm), _pi(rowptr), 1 if mean else 0,
+                                    _p(out3), out3.stride(1), out3.stride(0), B, n, D, _stream()))
+    return out3
+
+
+def edge_combine(base3, extra3, A3, ia, sa, C3, ic, out3=None):
+    """out[b,e] = base[b,e] + extra[b,e] + A[b, ia[e]] * sa[ia[e]] + C[b, ic[e]]  (operands optional)."""
+    ref = base3 if base3 is not None else extra3
+    if ref is not None:
+        B, E, D = ref.shape
+    else:
+        B, E, D = (A3 if A3 is not None else C3).shape[0], ia.numel() if ia is not None else ic.numel(), \
+            (A3 if A3 is not None else C3).shape[2]
+    for t in (base3, extra3):
+        assert t is None or t.is_contiguous()
+    if out3 is None:
+        out3 = torch.empty(B, E, D, dtype=torch.float32, device=(A3 if ref is None else ref).device)
+    _check(lib().gcl_edge_combine(
+        _p(base3), _p(extra3), _p(A3), A3.stride(1) if A3 is not None else 0, A3.stride(0) if A3 is not None else 0,
+        _pi(ia), _p(sa), _p(C3), C3.stride(1) if C3 is not None else 0, C3.stride(0) if C3 is not None else 0, _pi(ic),
+        _p(out3), B, E, D, _stream()))
+    return out3
+
+
+def act_fwd(x, act, slope=None):
+    y = torch.empty_like(x)
+    assert x.is_contiguous()
+    _check(lib().gcl_act_fwd(_p(x), _p(y), x.numel(), int(act), _p(slope), _stream()))
+    return y
+
+
+def act_bwd(x, dy, act, slope=None, d_slope=None):
+    assert x.is_contiguous() and dy.is_contiguous()
+    dx = torch.empty_like(x)
+    ws = workspace(lib().gcl_act_bwd_ws_bytes(), x.device)
+    _check(lib().gcl_act_bwd(_p(x), _p(dy), _p(dx), x.numel(), int(act), _p(slope), _p(d_slope), ws.data_ptr(), ws.numel(),
+                             _stream()))
+    return dx

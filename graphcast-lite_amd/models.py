@@ -5,6 +5,8 @@ Same class names, constructor arguments, attribute names and state-dict keys as 
 
   MLP               src/models.py:54-109     `MLP.{i}.weight|bias`
   SparseGATConv     src/models.py:112-151
+  InteractionNet*   src/models.py:166-285    `layers.edge_encoder.0.*`, `layers.steps.{k}.edge_mlp|node_mlp.{0,2}.*`,
+                                             `layers.steps.{k}.edge_norm|node_norm.*`
   GraphLayer        src/models.py:289-440    `activation.weight`, `layers.{i}.lin.weight|bias|att_*`
   Model             src/models.py:443-473    `mlp.*`, `graph_layer.*`
   WeatherPrediction src/models.py:476-927    `encoder|processor|decoder.*`, `_processing_edge_features`
@@ -37,7 +39,8 @@ from .config import (
     PipelineConfig,
 )
 from .create_graphs import create_decoding_graph, create_encoding_graph, create_processing_graph
-from .functional import AssembleFn, GATLayerFn, Gather2Fn, GCNStackFn, GraphNormFn, LayerNormFn, MeanAggFn, MLPFn
+from .functional import (AssembleFn, EdgeLayout, GATLayerFn, Gather2Fn, GCNStackFn, GraphNormFn, InteractionNetFn,
+                         LayerNormFn, MeanAggFn, MLPFn)
 from .mesh import get_hierarchy_of_triangular_meshes_for_sphere, get_mesh_lat_long, prune_mesh_to_region
 
 
@@ -126,8 +129,9 @@ class GATConv(nn.Module):
         _glorot_(self.att_src)
         _glorot_(self.att_dst)
 
-    def _run(self, x, edge_index, slope, want_alpha):
+    def _run(self, x, edge_index, slope, want_alpha, act=None):
         g = _graphs.get(edge_index, _num_nodes(x), hip.GRAPH_GAT)
+        self._in_act = act
         y, alpha = GATLayerFn.apply(x, self, g, self.heads, want_alpha, slope, self.lin.weight, self.att_src,
                                     self.att_dst, self.bias)
         return y, alpha, g
@@ -196,11 +200,97 @@ class SimpleConv(nn.Module):
 
 
 def _get_activation(name: str = "prelu"):
+    """`src/models.py:154-163`.  The modules only carry the parameters / state-dict keys; the kernels
+    apply the activation while loading the next layer's input (`_act_spec`)."""
+    if name in ("swish", "silu"):
+        return nn.SiLU()
     if name == "prelu":
         return nn.PReLU()
-    if name in ("swish", "silu", "relu"):
-        raise NotImplementedError(f"activation {name!r} is not on the HIP path (PReLU stacks only)")
+    if name == "relu":
+        return nn.ReLU()
     raise ValueError(f"Unknown activation: {name}")
+
+
+def _act_spec(owner: nn.Module, act: nn.Module):
+    """Sets `owner.act_kind` / `owner.const_slope` for the HIP Functions and returns the learnable
+    slope (or None).  ReLU runs as a PReLU with a constant zero slope."""
+    owner.act_kind = hip.ACT_SILU if isinstance(act, nn.SiLU) else hip.ACT_PRELU
+    if isinstance(act, nn.ReLU):
+        owner.register_buffer("const_slope", torch.zeros(1), persistent=False)
+    else:
+        owner.const_slope = None
+    return act.weight if isinstance(act, nn.PReLU) else None
+
+
+class InteractionNetLayer(nn.Module):
+    """Parameter holder of one message-passing step with the reference's keys (`src/models.py:166-204`):
+    `edge_mlp.{0,2}`, `node_mlp.{0,2}`, `edge_norm` (graph mode), `node_norm` (node mode).  The
+    compute is `functional.InteractionNetFn`, run by the processor over all steps."""
+
+    def __init__(self, node_dim: int, edge_dim: int, hidden_dim: int, activation: str = "swish",
+                 use_layer_norm: bool = True):
+        super().__init__()
+        if not (node_dim == edge_dim == hidden_dim):
+            raise NotImplementedError("InteractionNet on the HIP path needs node = edge = hidden width "
+                                      "(what GraphLayer builds, src/models.py:390-398)")
+        act = _get_activation(activation)  # one instance inside both MLPs (src/models.py:184-198)
+        self.edge_mlp = nn.Sequential(nn.Linear(node_dim * 2 + edge_dim, hidden_dim), act, nn.Linear(hidden_dim, edge_dim))
+        self.node_mlp = nn.Sequential(nn.Linear(node_dim + edge_dim, hidden_dim), act, nn.Linear(hidden_dim, node_dim))
+        self.use_layer_norm = use_layer_norm
+        if use_layer_norm:
+            self.edge_norm = LayerNorm(edge_dim, mode="graph")
+            self.node_norm = LayerNorm(node_dim, mode="node")
+
+    def step_params(self):
+        act = self.edge_mlp[1]
+        ln = self.use_layer_norm
+        return [self.edge_mlp[0].weight, self.edge_mlp[0].bias, self.edge_mlp[2].weight, self.edge_mlp[2].bias,
+                self.node_mlp[0].weight, self.node_mlp[0].bias, self.node_mlp[2].weight, self.node_mlp[2].bias,
+                act.weight if isinstance(act, nn.PReLU) else None,
+                self.edge_norm.weight if ln else None, self.edge_norm.bias if ln else None,
+                self.node_norm.weight if ln else None, self.node_norm.bias if ln else None]
+
+
+class InteractionNetProcessor(nn.Module):
+    """`src/models.py:239-285`: edge encoder (raw 4-D edge features -> latent) + N unshared steps."""
+
+    def __init__(self, node_dim: int, raw_edge_dim: int, edge_latent_dim: int, hidden_dim: int, num_steps: int,
+                 activation: str = "swish", use_layer_norm: bool = True):
+        super().__init__()
+        if node_dim % 4 != 0:
+            raise NotImplementedError("InteractionNet on the HIP path needs a latent width that is a multiple of 4")
+        self.edge_encoder = nn.Sequential(nn.Linear(raw_edge_dim, edge_latent_dim), _get_activation(activation))
+        self.steps = nn.ModuleList([
+            InteractionNetLayer(node_dim, edge_latent_dim, hidden_dim, activation, use_layer_norm)
+            for _ in range(num_steps)])
+        self.use_layer_norm = use_layer_norm
+        _act_spec(self, self.edge_encoder[1])
+        self._layout = None  # (edge_index, raw features) -> receiver-sorted layout, built once
+
+    def _edge_layout(self, edge_index, edge_attr_raw, n, device):
+        c = self._layout
+        if c is None or c[0] is not edge_index or c[1] is not edge_attr_raw or c[2].n != n:
+            lay = EdgeLayout(edge_index, n, device)
+            raw = edge_attr_raw.detach().to(device=device, dtype=torch.float32)[lay.order].contiguous()
+            pad = (-raw.shape[1]) % 4  # the dense kernels read 16-byte rows
+            if pad:
+                raw = torch.nn.functional.pad(raw, (0, pad))
+            self._layout = c = (edge_index, edge_attr_raw, lay, raw, pad)
+        return c[2], c[3], c[4]
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr_raw: torch.Tensor):
+        lay, raw, pad = self._edge_layout(edge_index, edge_attr_raw, _num_nodes(x), x.device)
+        enc_W = self.edge_encoder[0].weight
+        if pad:
+            raise NotImplementedError("edge_feature_dim must be a multiple of 4 on the HIP path")
+        enc_act = self.edge_encoder[1]
+        params = [enc_W, self.edge_encoder[0].bias, enc_act.weight if isinstance(enc_act, nn.PReLU) else None]
+        for st in self.steps:
+            params += st.step_params()
+        if self.const_slope is not None:
+            raise NotImplementedError("InteractionNet with ReLU is not on the HIP path (swish / prelu are)")
+        eps = self.steps[0].node_norm.eps if self.use_layer_norm else 1e-5
+        return InteractionNetFn.apply(x, self, lay, raw, len(self.steps), self.act_kind, self.use_layer_norm, eps, *params)
 
 
 class MLP(nn.Module):
@@ -250,6 +340,7 @@ class GraphLayer(nn.Module):
             self.layers = SimpleConv(aggr="mean")
         elif lt in (GraphLayerType.ConvGCN, GraphLayerType.GATConv, GraphLayerType.SparseGATConv):
             self.activation = _get_activation(graph_config.activation or "prelu")
+            _act_spec(self, self.activation)
             self.output_dim = graph_config.output_dim
             self.layers = nn.ModuleList()
             hidden = list(graph_config.hidden_dims or [])
@@ -270,12 +361,24 @@ class GraphLayer(nn.Module):
                         self.layers.append(self.activation)  # one shared PReLU instance (src/models.py:316-328)
             if graph_config.use_layer_norm:
                 self.layers.append(LayerNorm(in_channels=graph_config.output_dim, mode=graph_config.layer_norm_mode))
-        elif lt == GraphLayerType.InteractionNet:
-            raise NotImplementedError(
-                "InteractionNet is outside this build's hot path (SURVEY.md §8f next #1)")
+        elif lt == GraphLayerType.InteractionNet:  # src/models.py:376-398
+            self.output_dim = graph_config.output_dim
+            assert graph_config.output_dim == input_dim, (
+                f"InteractionNet requires output_dim ({graph_config.output_dim}) == input_dim ({input_dim}) "
+                f"(residual connections)")
+            use_ln = graph_config.use_layer_norm if graph_config.use_layer_norm is not None else True
+            self.layers = InteractionNetProcessor(
+                node_dim=input_dim, raw_edge_dim=graph_config.edge_feature_dim or 4, edge_latent_dim=input_dim,
+                hidden_dim=input_dim, num_steps=graph_config.num_message_passing_steps or 4,
+                activation=graph_config.activation or "swish", use_layer_norm=use_ln)
         else:
             print(graph_config.layer_type)
             raise NotImplementedError(f"Layer type {graph_config.layer_type} not supported.")
+
+    @property
+    def _slope(self):
+        """Learnable slope of the shared activation (PReLU only)."""
+        return self.activation.weight if isinstance(self.activation, nn.PReLU) else None
 
     def _final_ln(self) -> Optional[LayerNorm]:
         last = self.layers[len(self.layers) - 1]
@@ -284,6 +387,11 @@ class GraphLayer(nn.Module):
     def forward(self, X: torch.Tensor, edge_index: torch.Tensor, attention_threshold=0.0, **kwargs):
         if self.layer_type == GraphLayerType.SimpleConv:
             return self.layers(x=X, edge_index=edge_index)
+        if self.layer_type == GraphLayerType.InteractionNet:
+            edge_attr = kwargs.get("edge_attr", None)
+            if edge_attr is None:
+                raise ValueError("InteractionNet requires edge_attr (edge features)")
+            return self.layers(x=X, edge_index=edge_index, edge_attr_raw=edge_attr)
         n = _num_nodes(X)
         ln = self._final_ln()
         fuse_ln = ln is not None and ln.mode == "node"
@@ -293,7 +401,7 @@ class GraphLayer(nn.Module):
             params = []
             for c in convs:
                 params += [c.lin.weight, c.bias]
-            params.append(self.activation.weight if len(convs) > 1 else None)
+            params.append(self._slope if len(convs) > 1 else None)
             if fuse_ln:
                 params += [ln.weight, ln.bias]
             g = _graphs.get(edge_index, n, hip.GRAPH_GCN)
@@ -303,11 +411,13 @@ class GraphLayer(nn.Module):
             return X
 
         if self.layer_type == GraphLayerType.GATConv:
-            slope = None
+            slope, act = None, hip.ACT_NONE
             for layer in self.layers:
                 if isinstance(layer, GATConv):
-                    X, _, _ = layer._run(X, edge_index, slope, False)
-                    slope = self.activation.weight  # next conv applies the shared PReLU on load
+                    X, _, _ = layer._run(X, edge_index, slope, False, act)
+                    # the next conv applies the shared activation while loading its input
+                    slope = self._slope if self._slope is not None else self.const_slope
+                    act = self.act_kind
                 elif isinstance(layer, LayerNorm):
                     X = layer(X)
             return X
@@ -501,6 +611,10 @@ class WeatherPrediction(nn.Module):
             processed, new_edge_index = self.processor.forward(
                 X=mesh_lat, edge_index=self.processing_graph, attention_threshold=attention_threshold, **kwargs)
             self.processing_graph = new_edge_index
+        elif self.using_interaction_net:
+            processed = self.processor.forward(X=mesh_lat, edge_index=self.processing_graph,
+                                               attention_threshold=attention_threshold,
+                                               edge_attr=self._processing_edge_features)
         else:
             processed = self.processor.forward(X=mesh_lat, edge_index=self.processing_graph,
                                                attention_threshold=attention_threshold)
@@ -526,6 +640,10 @@ class WeatherPrediction(nn.Module):
                 X=mesh_node_features, edge_index=self.processing_graph, attention_threshold=attention_threshold,
                 **kwargs)
             self.processing_graph = new_edge_index
+        elif self.using_interaction_net:
+            processed = self.processor.forward(
+                X=mesh_node_features, edge_index=self.processing_graph, attention_threshold=attention_threshold,
+                edge_attr=self._processing_edge_features)
         else:
             processed = self.processor.forward(
                 X=mesh_node_features, edge_index=self.processing_graph, attention_threshold=attention_threshold)

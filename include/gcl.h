@@ -114,6 +114,33 @@ int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W, const floa
                        int32_t accumulate, void* ws, size_t ws_bytes, gcl_stream_t stream);
 size_t gcl_linear_bwd_all_ws_bytes(int64_t rows, int32_t Fin, int32_t Fout);
 
+/* General form of the three calls above, for wide layers and fused operands (the InteractionNet
+ * processor, src/models.py:185-233, and the 256-wide MLPs): any Fin / Fout, the weight may be a
+ * column block of a wider matrix (row stride ldw >= Fin, e.g. one third of edge_mlp[0].weight
+ * [256, 768]), the activation on the input is selectable, and an addend [rows, Fout] can be summed
+ * in the epilogue (residuals; the second half of a split contraction).
+ * Shapes that fit the resident-weight-panel kernel run there; wider ones (K or N > 256, or a panel
+ * beyond 160 KiB of LDS) run a 128x128-tile contraction that needs Fin % 4 == 0 and 16-B aligned
+ * rows.  All use the exact-fp32 matrix instruction. */
+#define GCL_ACT_NONE 0
+#define GCL_ACT_PRELU 1 /* one learnable slope (nn.PReLU()); needs the slope pointer */
+#define GCL_ACT_SILU 2  /* x * sigmoid(x)  (nn.SiLU, "swish": src/models.py:154-163) */
+/* y = act(x) W^T + bias + addend */
+int gcl_dense_fwd(const float* x, int64_t ldx, int32_t act, const float* slope, const float* W,
+                  int64_t ldw, const float* bias, const float* addend, int64_t ldadd, float* y,
+                  int64_t ldy, int64_t rows, int32_t Fin, int32_t Fout, gcl_stream_t stream);
+/* dx = (dy W) * act'(z) + addend, z = the pre-activation the forward call read as x; PReLU adds
+ * its slope gradient into *d_slope (may be NULL).  ws: gcl_linear_bwd_ws_bytes(rows, Fin, Fout). */
+int gcl_dense_bwd_dx(const float* dy, int64_t lddy, const float* W, int64_t ldw, const float* z,
+                     int64_t ldz, int32_t act, const float* slope, float* d_slope,
+                     const float* addend, int64_t ldadd, float* dx, int64_t lddx, int64_t rows,
+                     int32_t Fin, int32_t Fout, void* ws, size_t ws_bytes, gcl_stream_t stream);
+/* dW[o, c] (+)= sum_r dy[r, o] act(x[r, c]) (row stride lddw), db (+)= colsum(dy) (may be NULL) */
+int gcl_dense_bwd_dw(const float* dy, int64_t lddy, const float* x, int64_t ldx, int32_t act,
+                     const float* slope, float* dW, int64_t lddw, float* db, int64_t rows,
+                     int32_t Fin, int32_t Fout, int32_t accumulate, void* ws, size_t ws_bytes,
+                     gcl_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Sparse aggregation over the CSR  y[b,i,:] = sum_{e in row i} w_e * h[b, col_e, :] (+ bias)
  * Replaces the index_select -> multiply -> scatter_add_ of PyG propagate for GCNConv
@@ -227,6 +254,32 @@ int gcl_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t coun
 /* Strided row copy  dst[b, i, 0:F] = src[b, i, 0:F]  (stage glue: src/models.py:837-838,860-862). */
 int gcl_copy_rows(const float* src, int64_t lds, int64_t bss, float* dst, int64_t ldd, int64_t bsd,
                   int32_t B, int32_t rows, int32_t F, gcl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Edge-wise glue of the InteractionNet processor (src/models.py:206-236); csrc/interaction.hip.
+ * Index arrays are int32 device arrays; rows are [.., D] with D % 4 == 0 and 16-B alignment.
+ * ------------------------------------------------------------------------------------------- */
+/* out[b,i,:] = sum (mean != 0: mean, empty segment -> 0) over k in [rowptr[i], rowptr[i+1]) of
+ * src[b, perm ? perm[k] : k, :].  scatter(edge_update, receivers, reduce="mean")
+ * (src/models.py:221) on receiver-sorted edges, and the backward of the x[senders] /
+ * x[receivers] gathers (src/models.py:216). */
+int gcl_segment_reduce(const float* src, int64_t ld_src, int64_t bs_src, const int32_t* perm,
+                       const int32_t* rowptr /*[n+1]*/, int32_t mean, float* out, int64_t ld_out,
+                       int64_t bs_out, int32_t B, int32_t n, int32_t D, gcl_stream_t stream);
+/* out[b,e,:] = base[b,e,:] + extra[b,e,:] + A[b, ia[e], :] * sa[ia[e]] + C[b, ic[e], :]
+ * (every operand optional; base / extra / out contiguous [B,E,D]).  Forward: the sender /
+ * receiver terms of the first edge-MLP layer; backward: d(aggregated)[receivers] / deg. */
+int gcl_edge_combine(const float* base, const float* extra, const float* A, int64_t lda, int64_t bsa,
+                     const int32_t* ia, const float* sa, const float* C, int64_t ldc, int64_t bsc,
+                     const int32_t* ic, float* out, int32_t B, int64_t E, int32_t D,
+                     gcl_stream_t stream);
+/* Elementwise activation where its output must exist in memory (edge_encoder, src/models.py:251):
+ * y = act(x);  dx = dy * act'(x), PReLU adds its slope gradient into *d_slope. */
+int gcl_act_fwd(const float* x, float* y, int64_t count, int32_t act, const float* slope,
+                gcl_stream_t stream);
+int gcl_act_bwd(const float* x, const float* dy, float* dx, int64_t count, int32_t act,
+                const float* slope, float* d_slope, void* ws, size_t ws_bytes, gcl_stream_t stream);
+size_t gcl_act_bwd_ws_bytes(void);
 
 /* One autoregressive advance of the observation window, fused (scripts/predict.py:512-535 and the
  * same steps in src/train.py:203-228): step_out = residual ? x_last + delta : delta; static channels

@@ -10,6 +10,8 @@ by `state_dict()` / `load_state_dict()`:
                                           `layers.{i}.bias`, `layers.{i}.att_src|att_dst`,
                                           `layers.{odd}.weight` (alias of the shared PReLU),
                                           LayerNorm at `layers.{last}.weight|bias`
+  InteractionNet `src/models.py:166-285`  `layers.edge_encoder.0.*`, `layers.steps.{k}.edge_mlp.{0,2}.*`,
+                                          `layers.steps.{k}.node_mlp.{0,2}.*`, `...edge_norm.*`, `...node_norm.*`
   Model          `src/models.py:443-473`  `mlp.*`, `graph_layer.*`
   WeatherPrediction `src/models.py:476-927` `encoder.*`, `processor.*`, `decoder.*`,
                                           buffer `_processing_edge_features`
@@ -97,6 +99,65 @@ class OSimpleConv(nn.Module):
         return P.simple_conv_mean(x, edge_index)
 
 
+def get_activation(name: str = "prelu") -> nn.Module:
+    """`src/models.py:154-163`."""
+    if name in ("swish", "silu"):
+        return nn.SiLU()
+    if name == "prelu":
+        return nn.PReLU()
+    if name == "relu":
+        return nn.ReLU()
+    raise ValueError(f"Unknown activation: {name}")
+
+
+class OInteractionNetLayer(nn.Module):
+    """One message-passing step, `src/models.py:166-236`: edge update from [sender | receiver | edge],
+    mean over incoming edges, node update from [node | aggregate], residuals, then graph-mode LN on
+    the edges and node-mode LN on the nodes."""
+
+    def __init__(self, node_dim: int, edge_dim: int, hidden_dim: int, activation: str = "swish",
+                 use_layer_norm: bool = True):
+        super().__init__()
+        act = get_activation(activation)  # one instance inside both MLPs (src/models.py:184-198)
+        self.edge_mlp = nn.Sequential(nn.Linear(2 * node_dim + edge_dim, hidden_dim), act, nn.Linear(hidden_dim, edge_dim))
+        self.node_mlp = nn.Sequential(nn.Linear(node_dim + edge_dim, hidden_dim), act, nn.Linear(hidden_dim, node_dim))
+        self.use_layer_norm = use_layer_norm
+        if use_layer_norm:
+            self.edge_norm = OLayerNorm(edge_dim, mode="graph")
+            self.node_norm = OLayerNorm(node_dim, mode="node")
+
+    def forward(self, x, edge_index, edge_attr):
+        snd, rcv = edge_index[0], edge_index[1]
+        n = x.shape[-2]
+        upd_e = self.edge_mlp(torch.cat([x[..., snd, :], x[..., rcv, :], edge_attr], dim=-1))
+        agg = P.scatter_mean_rows(upd_e, rcv, n)
+        upd_x = self.node_mlp(torch.cat([x, agg], dim=-1))
+        new_e, new_x = edge_attr + upd_e, x + upd_x
+        if self.use_layer_norm:
+            new_e, new_x = self.edge_norm(new_e), self.node_norm(new_x)
+        return new_x, new_e
+
+
+class OInteractionNetProcessor(nn.Module):
+    """`src/models.py:239-285`: raw edge features -> latent (Linear + activation), then N unshared steps."""
+
+    def __init__(self, node_dim, raw_edge_dim, edge_latent_dim, hidden_dim, num_steps, activation="swish",
+                 use_layer_norm=True):
+        super().__init__()
+        self.edge_encoder = nn.Sequential(nn.Linear(raw_edge_dim, edge_latent_dim), get_activation(activation))
+        self.steps = nn.ModuleList([
+            OInteractionNetLayer(node_dim, edge_latent_dim, hidden_dim, activation, use_layer_norm)
+            for _ in range(num_steps)])
+
+    def forward(self, x, edge_index, edge_attr_raw):
+        e = self.edge_encoder(edge_attr_raw)
+        if x.dim() == 3:  # batched samples share the raw edge features
+            e = e.unsqueeze(0).expand(x.shape[0], -1, -1)
+        for step in self.steps:
+            x, e = step(x, edge_index, e)
+        return x
+
+
 class MLP(nn.Module):
     def __init__(self, mlp_config, input_dim: int):
         super().__init__()
@@ -125,11 +186,18 @@ class GraphLayer(nn.Module):
             self.output_dim = input_dim
             self.layers = OSimpleConv()
             return
+        if lt == "interaction_net":  # src/models.py:376-398
+            self.output_dim = graph_config.output_dim
+            assert graph_config.output_dim == input_dim, "InteractionNet requires output_dim == input_dim (residuals)"
+            use_ln = graph_config.use_layer_norm if graph_config.use_layer_norm is not None else True
+            self.layers = OInteractionNetProcessor(
+                node_dim=input_dim, raw_edge_dim=graph_config.edge_feature_dim or 4, edge_latent_dim=input_dim,
+                hidden_dim=input_dim, num_steps=graph_config.num_message_passing_steps or 4,
+                activation=graph_config.activation or "swish", use_layer_norm=use_ln)
+            return
         if lt not in ("conv_gcn", "conv_gat", "sparse_gat"):
             raise NotImplementedError(f"Layer type {graph_config.layer_type} not supported.")
-        if (graph_config.activation or "prelu") != "prelu":
-            raise NotImplementedError("the oracle restates the PReLU stacks only")
-        self.activation = nn.PReLU()
+        self.activation = get_activation(graph_config.activation or "prelu")
         self.output_dim = graph_config.output_dim
         self.layers = nn.ModuleList()
         hidden = list(graph_config.hidden_dims or [])
@@ -153,6 +221,11 @@ class GraphLayer(nn.Module):
     def forward(self, X, edge_index, attention_threshold=0.0, **kwargs):
         if self.layer_type == "simple_conv":
             return self.layers(X, edge_index)
+        if self.layer_type == "interaction_net":
+            edge_attr = kwargs.get("edge_attr", None)
+            if edge_attr is None:
+                raise ValueError("InteractionNet requires edge_attr (edge features)")
+            return self.layers(X, edge_index, edge_attr)
         if self.layer_type == "sparse_gat":
             for layer in self.layers:
                 if isinstance(layer, OSparseGATConv):
@@ -205,6 +278,7 @@ class WeatherPrediction(nn.Module):
             self._processing_edge_features = None
         lt = pipeline_config.processor.gcn.layer_type
         self.using_sparse_gat = getattr(lt, "value", lt) == "sparse_gat"
+        self.using_interaction_net = getattr(lt, "value", lt) == "interaction_net"
         enc_in = self.total_feature_size + init_grid_features.shape[1]
         self.encoder = Model(pipeline_config.encoder, enc_in)
         self.processor = Model(pipeline_config.processor, self.encoder.output_dim)
@@ -231,6 +305,9 @@ class WeatherPrediction(nn.Module):
             mesh_out, new_graph = self.processor(
                 mesh_lat, self.processing_graph, attention_threshold=attention_threshold, **kwargs)
             self.processing_graph = new_graph
+        elif self.using_interaction_net:
+            mesh_out = self.processor(mesh_lat, self.processing_graph, attention_threshold=attention_threshold,
+                                      edge_attr=self._processing_edge_features)
         else:
             mesh_out = self.processor(mesh_lat, self.processing_graph, attention_threshold=attention_threshold)
         dec = self.decoder(torch.cat((grid_lat, mesh_out), dim=-2), self.decoding_graph)

@@ -159,3 +159,14 @@ def pyg_layer_norm(x: torch.Tensor, weight, bias, mode: str = "graph", eps: floa
 def prelu(x: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
     """`nn.PReLU()` with one scalar slope (Appendix A.5)."""
     return F.prelu(x, a)
+
+
+def scatter_mean_rows(values: torch.Tensor, index: torch.Tensor, n: int) -> torch.Tensor:
+    """`torch_geometric.utils.scatter(values, index, dim=0, dim_size=n, reduce="mean")` as the
+    reference calls it on edge rows (`src/models.py:220-221`): per-target sum / max(count, 1),
+    rows without any source are exact zeros.  values `[..., E, D]`, index `[E]`."""
+    out = torch.zeros(values.shape[:-2] + (n, values.shape[-1]), dtype=values.dtype, device=values.device)
+    out.index_add_(-2, index, values)
+    cnt = torch.zeros(n, dtype=values.dtype, device=values.device).index_add_(
+        0, index, torch.ones(index.numel(), dtype=values.dtype, device=values.device))
+    return out / cnt.clamp(min=1).unsqueeze(-1)

@@ -52,7 +52,9 @@ def data(cfg, G, B, seed=1234):
 
 @pytest.mark.parametrize("name,levels,B", [("baseline", [1, 2], 2), ("baseline", [3, 5], 3), ("attention", [1, 2], 2),
                                            ("attention", [3, 5], 2), ("attention_h4", [1, 2], 2),
-                                           ("sparse_attention", [1, 2], 2), ("wb2_512x256_19f_ar", [1, 2], 2)])
+                                           ("sparse_attention", [1, 2], 2), ("wb2_512x256_19f_ar", [1, 2], 2),
+                                           ("region_krsk_cds_19f", [1, 2], 2), ("region_krsk_cds_19f", [2, 3], 1),
+                                           ("wb2_512x256_19f_ar_v2", [1, 2], 1)])
 def test_forward_backward_parity(name, levels, B):
     from graphcast_lite_amd.train import batch_loss, get_lat_weights
 
@@ -403,3 +405,46 @@ def test_fused_adam_state_interchanges_with_torch_adam(tmp_path):
     step2(X.to(DEV), y.to(DEV))
     for n_, p in m2.named_parameters():
         assert rel(p, od[n_]) < 1e-5, n_
+
+
+@pytest.mark.parametrize("act", ["relu", "prelu", "swish"])
+@pytest.mark.parametrize("family", ["gcn", "gat", "interaction"])
+def test_activation_variants(family, act):
+    """`_get_activation` (src/models.py:154-163): swish / relu / prelu inside the GCN / GAT stacks and the
+    InteractionNet MLPs (relu is not offered for InteractionNet on the HIP path)."""
+    from graphcast_lite_amd.train import batch_loss, get_lat_weights
+
+    if family == "interaction" and act == "relu":
+        pytest.skip("InteractionNet + relu raises NotImplementedError by design")
+    name = {"gcn": "baseline", "gat": "attention", "interaction": "region_krsk_cds_19f"}[family]
+    import conftest
+    base = conftest.experiment
+
+    def patched(nm, mesh_levels=None):
+        cfg = base(nm, mesh_levels=mesh_levels)
+        for blk in (cfg.pipeline.encoder.gcn, cfg.pipeline.processor.gcn, cfg.pipeline.decoder.gcn):
+            blk.activation = act
+        return cfg
+
+    global experiment
+    saved, experiment = experiment, patched
+    try:
+        cfg, m, o = make_pair(name, [1, 2])
+    finally:
+        experiment = saved
+    X, y = data(cfg, m._num_grid_nodes, 2)
+    assert rel(m(X.to(DEV)), o(X)) < 1e-5
+    lw = T.get_lat_weights(32, 64)
+    T.train_step_loss(o, X, y, lat_weights=lw).backward()
+    batch_loss(m, X.to(DEV), y.to(DEV), lat_weights=get_lat_weights(32, 64, DEV)).backward()
+    og = dict(o.named_parameters())
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in og.values() if p.grad is not None)))
+    for n_, p in m.named_parameters():
+        if og[n_].grad is None:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, n_
+            continue
+        d = float((p.grad.double().cpu() - og[n_].grad.double()).norm())
+        # ReLU's derivative jumps by the full gradient at 0: a pre-activation that rounds to the other
+        # side of 0 in one of the two fp32 implementations flips a whole element (PReLU: 1 - slope of it)
+        tol = 3e-3 if act == "relu" else 1e-4
+        assert d <= tol * float(og[n_].grad.double().norm()) + 1e-6 * gn, (n_, d)

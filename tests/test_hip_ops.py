@@ -341,3 +341,103 @@ def test_adam_matches_torch(hip):
         opt.step()
         H.adam_step(p, (2 * g * step).to(DEV), m, v, 1e-3, 0.9, 0.999, 1e-8, 0.0, step, grad_scale=0.5)
     assert rel(p, pt) < 1e-6
+
+
+def _act_ref(x, act, a):
+    if act == 0:
+        return x
+    if act == 1:
+        return torch.where(x > 0, x, a * x)
+    return x * torch.sigmoid(x)
+
+
+@pytest.mark.parametrize("rows,Fin,Fout", [(1000, 256, 256), (333, 512, 256), (700, 256, 512), (129, 260, 132),
+                                           (5000, 128, 64), (64, 768, 256), (1, 256, 256)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_dense_fwd_bwd_wide(hip, rows, Fin, Fout, act):
+    """gcl_dense_*: wide layers (tiled contraction), SiLU / PReLU on load, weight column blocks (ldw > Fin),
+    addend epilogues, gradient column blocks - against fp64 torch autograd."""
+    Wfull = rnd(Fout, Fin + 64, seed=2, scale=0.1)
+    x = rnd(rows, Fin, seed=1).double().requires_grad_()
+    W = Wfull[:, 32:32 + Fin].double().clone().requires_grad_()
+    b = rnd(Fout, seed=3).double().requires_grad_()
+    add = rnd(rows, Fout, seed=4).double()
+    a = torch.tensor([0.25], dtype=torch.float64, requires_grad=True)
+    dy = rnd(rows, Fout, seed=5).double()
+    y = _act_ref(x, act, a) @ W.t() + b + add
+    y.backward(dy)
+
+    Wd = Wfull.to(DEV)[:, 32:32 + Fin]  # a column block: row stride Fin + 64
+    xd, bd, addd, dyd = x.detach().float().to(DEV), b.detach().float().to(DEV), add.float().to(DEV), dy.float().to(DEV)
+    ad = a.detach().float().to(DEV) if act == 1 else None
+    yd = hip.dense_fwd(xd, Wd, bd, act, ad, addend=addd)
+    assert rel(yd, y) < TOL
+    # dx wrt the pre-activation x, plus an addend (a residual gradient)
+    radd = rnd(rows, Fin, seed=6)
+    d_slope = torch.zeros(1, device=DEV) if act == 1 else None
+    dxd = hip.dense_bwd_dx(dyd, Wd, xd if act else None, act, ad, d_slope, addend=radd.to(DEV))
+    assert rel(dxd, x.grad + radd.double()) < TOL
+    if act == 1:
+        assert abs(d_slope.item() - a.grad.item()) < 1e-4 * max(1.0, abs(a.grad.item()))
+    # dW into a column block of a wider gradient, accumulate on top of existing content
+    dWfull = torch.ones(Fout, Fin + 64, device=DEV)
+    dbd = torch.ones(Fout, device=DEV)
+    hip.dense_bwd_dw(dyd, xd, dWfull[:, 32:32 + Fin], dbd, True, act, ad)
+    assert rel(dWfull[:, 32:32 + Fin] - 1.0, W.grad) < 5 * TOL
+    assert rel(dbd - 1.0, b.grad) < 5 * TOL
+    assert (dWfull[:, :32] == 1).all() and (dWfull[:, 32 + Fin:] == 1).all()
+
+
+def _random_segments(n, E, seed):
+    g = torch.Generator().manual_seed(seed)
+    rcv = torch.sort(torch.randint(0, n, (E,), generator=g)).values
+    rcv[rcv == n // 2] = n // 2 + 1 if n // 2 + 1 < n else 0  # leave at least one empty segment
+    rcv = torch.sort(rcv).values
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(torch.bincount(rcv, minlength=n), 0)
+    return rcv, rowptr
+
+
+@pytest.mark.parametrize("B,n,E,D", [(2, 50, 400, 256), (1, 7, 30, 128), (3, 33, 100, 64), (2, 40, 300, 20)])
+def test_segment_reduce_and_edge_combine(hip, B, n, E, D):
+    """gcl_segment_reduce == scatter(..., reduce="mean"/"sum") on sorted segments (src/models.py:221), with and
+    without a permutation; gcl_edge_combine == base + extra + A[ia]*sa[ia] + C[ic]."""
+    rcv, rowptr = _random_segments(n, E, 3)
+    src = rnd(B, E, D, seed=1)
+    ref_mean = P.scatter_mean_rows(src, rcv, n)
+    i32 = lambda t: t.to(torch.int32).to(DEV)
+    got = hip.segment_reduce(src.to(DEV), None, i32(rowptr), True)
+    assert rel(got, ref_mean) < 1e-6
+    assert (got.cpu()[:, n // 2] == 0).all()  # empty segment -> exact zeros
+    # permuted sum into a column block of a wider output
+    perm = torch.randperm(E, generator=torch.Generator().manual_seed(9))
+    wide = torch.full((B, n, 2 * D), 5.0, device=DEV)
+    hip.segment_reduce(src.to(DEV), i32(perm), i32(rowptr), False, out3=wide[:, :, D:])
+    ref_sum = torch.zeros(B, n, D).index_add_(1, rcv, src[:, perm])
+    assert rel(wide[:, :, D:], ref_sum) < 1e-6 and (wide[:, :, :D] == 5.0).all()
+
+    A, Cc, base, extra = rnd(B, n, 2 * D, seed=4), rnd(B, n, D, seed=5), rnd(B, E, D, seed=6), rnd(B, E, D, seed=7)
+    snd = torch.randint(0, n, (E,), generator=torch.Generator().manual_seed(8))
+    sa = torch.rand(n, generator=torch.Generator().manual_seed(10)) + 0.5
+    Ad = A.to(DEV)
+    got = hip.edge_combine(base.to(DEV), extra.to(DEV), Ad[:, :, D:], i32(snd), sa.to(DEV), Cc.to(DEV), i32(rcv))
+    want = base + extra + A[:, snd, D:] * sa[snd].view(1, E, 1) + Cc[:, rcv]
+    assert rel(got, want) < 1e-6
+    got = hip.edge_combine(None, None, Ad[:, :, :D], i32(snd), None, None, None)
+    assert torch.equal(got.cpu(), A[:, snd, :D])
+
+
+@pytest.mark.parametrize("act", [1, 2])
+def test_act_fwd_bwd(hip, act):
+    x = rnd(1000, 64, seed=1).double().requires_grad_()
+    a = torch.tensor([0.3], dtype=torch.float64, requires_grad=True)
+    dy = rnd(1000, 64, seed=2).double()
+    y = _act_ref(x, act, a)
+    y.backward(dy)
+    ad = a.detach().float().to(DEV) if act == 1 else None
+    xd = x.detach().float().to(DEV)
+    assert rel(hip.act_fwd(xd, act, ad), y) < 1e-6
+    ds = torch.zeros(1, device=DEV) if act == 1 else None
+    assert rel(hip.act_bwd(xd, dy.float().to(DEV), act, ad, ds), x.grad) < 1e-6
+    if act == 1:
+        assert abs(ds.item() - a.grad.item()) < 1e-4 * abs(a.grad.item())
