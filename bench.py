@@ -96,7 +96,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="samples per GPU (default: 64 at 64x32, 8 at 512x256)")
     ap.add_argument("--config", default="baseline",
-                    choices=["baseline", "attention", "attention_h4", "sparse_attention", "wb2_512x256_19f_ar"])
+                    choices=["baseline", "attention", "attention_h4", "sparse_attention", "wb2_512x256_19f_ar",
+                             "wb2_512x256_19f_ar_v2", "region_krsk_cds_19f"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured hipGraph (1 GPU). Off by default: launches inside a "
@@ -118,7 +119,7 @@ def main():
 
     hip.lib()
     cfg, model, grid = build_model(args.config, dev)
-    B = args.batch or (8 if args.config == "wb2_512x256_19f_ar" else 64)
+    B = args.batch or {"wb2_512x256_19f_ar": 8, "wb2_512x256_19f_ar_v2": 1}.get(args.config, 64)
     G, M = model._num_grid_nodes, model._num_mesh_nodes
     X, y = synthetic_batch(cfg, G, B, seed=1234 + rank)  # every rank its own samples
     X, y = X.to(dev), y.to(dev)                           # resident in HBM before the timed region

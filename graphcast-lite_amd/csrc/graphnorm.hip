@@ -1,9 +1,9 @@
 // PyG LayerNorm(mode="graph") forward + backward (reference construction
 // src/models.py:102-104,368-374): statistics over ALL n*F elements of one sample's tensor,
 //   y = (x - mean) / (std_biased + eps) * gamma + beta        (eps added to the std, not inside sqrt)
-// per sample under batching.  Two launches per direction: per-(sample, chunk) partial sums in
-// fp64 (the variance is formed as E[x^2] - mean^2, so the sums must not lose bits), then an apply
-// pass that re-derives the per-sample scalars from the partials in a fixed order.
+// per sample under batching.  Three launches per direction: per-(sample, chunk) partial sums in
+// fp64 (the variance is formed as E[x^2] - mean^2, so the sums must not lose bits), a tiny
+// fixed-order reduction of the partials to per-sample sums, then the apply pass.
 //   stats[b] = (mean, 1/(std + eps))
 // backward, with g = dy*gamma, d = std + eps, N = n*F:
 //   dx = (g - mean(g)) / d - (x - mean) * sum(g (x - mean)) / (N std d^2)
@@ -14,11 +14,16 @@
 
 namespace {
 
-constexpr int kGnChunks = 64;  // partial sums per sample
+constexpr int kGnChunks = 2048;  // at most this many partial sums per sample (a sample of 84M elements still fills the chip)
+static inline int gn_chunks(int64_t n, int F) {  // ~16K elements per chunk
+  const int64_t c = (n * F + 16383) / 16384;
+  return (int)(c < 1 ? 1 : c > kGnChunks ? kGnChunks : c);
+}
 
 // part[b][chunk][2] = (sum a, sum b) over the chunk's rows, with
 //   MODE 0: a = x, b = x^2          MODE 1: a = dy*gamma, b = dy*gamma*(x - mean)
-template <int MODE>
+// VEC: rows are read as float4 (F % 4 == 0, 16-B aligned rows).
+template <int MODE, bool VEC>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ X, int64_t ldx, int64_t bsx,
                                                          const float* __restrict__ dY, int64_t lddy, int64_t bsdy,
                                                          const float* __restrict__ gamma,
@@ -26,21 +31,41 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
                                                          int32_t n, int32_t F) {
   __shared__ double red[2][4];
   const int b = blockIdx.y, chunk = blockIdx.x;
-  const int rows_per = (n + kGnChunks - 1) / kGnChunks;
-  const int r0 = chunk * rows_per, r1 = min(n, r0 + rows_per);
+  const int rows_per = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int r0 = min(n, chunk * rows_per), r1 = min(n, r0 + rows_per);
   const float mean = (MODE == 1) ? stats[2 * b] : 0.f;
   double sa = 0.0, sb = 0.0;
-  const int64_t total = (int64_t)(r1 > r0 ? r1 - r0 : 0) * F;
-  for (int64_t idx = threadIdx.x; idx < total; idx += 256) {
-    const int r = r0 + (int)(idx / F), c = (int)(idx % F);
-    const float x = X[(int64_t)b * bsx + (int64_t)r * ldx + c];
-    if (MODE == 0) {
-      sa += (double)x;
-      sb += (double)x * (double)x;
-    } else {
-      const float g = dY[(int64_t)b * bsdy + (int64_t)r * lddy + c] * gamma[c];
-      sa += (double)g;
-      sb += (double)g * (double)(x - mean);
+  if (VEC) {
+    const int F4 = F >> 2;
+    const int64_t total = (int64_t)(r1 - r0) * F4;
+    for (int64_t idx = threadIdx.x; idx < total; idx += 256) {
+      const int r = r0 + (int)(idx / F4), c = (int)(idx % F4) * 4;
+      const float4 x = *reinterpret_cast<const float4*>(X + (int64_t)b * bsx + (int64_t)r * ldx + c);
+      if (MODE == 0) {
+        sa += ((double)x.x + (double)x.y) + ((double)x.z + (double)x.w);
+        sb += ((double)x.x * (double)x.x + (double)x.y * (double)x.y) + ((double)x.z * (double)x.z + (double)x.w * (double)x.w);
+      } else {
+        const float4 d = *reinterpret_cast<const float4*>(dY + (int64_t)b * bsdy + (int64_t)r * lddy + c);
+        const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+        const float g0 = d.x * gm.x, g1 = d.y * gm.y, g2 = d.z * gm.z, g3 = d.w * gm.w;
+        sa += ((double)g0 + (double)g1) + ((double)g2 + (double)g3);
+        sb += ((double)g0 * (double)(x.x - mean) + (double)g1 * (double)(x.y - mean)) +
+              ((double)g2 * (double)(x.z - mean) + (double)g3 * (double)(x.w - mean));
+      }
+    }
+  } else {
+    const int64_t total = (int64_t)(r1 - r0) * F;
+    for (int64_t idx = threadIdx.x; idx < total; idx += 256) {
+      const int r = r0 + (int)(idx / F), c = (int)(idx % F);
+      const float x = X[(int64_t)b * bsx + (int64_t)r * ldx + c];
+      if (MODE == 0) {
+        sa += (double)x;
+        sb += (double)x * (double)x;
+      } else {
+        const float g = dY[(int64_t)b * bsdy + (int64_t)r * lddy + c] * gamma[c];
+        sa += (double)g;
+        sb += (double)g * (double)(x - mean);
+      }
     }
   }
   for (int off = 32; off > 0; off >>= 1) {
@@ -59,13 +84,34 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
   }
 }
 
-__device__ __forceinline__ void gn_sum_parts(const double* part, int b, double& s0, double& s1) {
-  s0 = 0.0;
-  s1 = 0.0;
-  for (int k = 0; k < kGnChunks; ++k) {  // fixed order: deterministic
+// fin[b][2] = the per-sample sums, reduced from the chunk partials in a fixed order
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, double* __restrict__ fin,
+                                                          int32_t nchunks) {
+  __shared__ double red[2][4];
+  const int b = blockIdx.x;
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = threadIdx.x; k < nchunks; k += 256) {
     s0 += part[((int64_t)b * kGnChunks + k) * 2];
     s1 += part[((int64_t)b * kGnChunks + k) * 2 + 1];
   }
+  for (int off = 32; off > 0; off >>= 1) {
+    s0 += __shfl_down(s0, off, 64);
+    s1 += __shfl_down(s1, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s0;
+    red[1][threadIdx.x >> 6] = s1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    fin[2 * b] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    fin[2 * b + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+__device__ __forceinline__ void gn_sum_parts(const double* fin, int b, double& s0, double& s1) {
+  s0 = fin[2 * b];
+  s1 = fin[2 * b + 1];
 }
 
 __global__ __launch_bounds__(256) void gn_fwd_apply_kernel(const float* __restrict__ X, int64_t ldx, int64_t bsx,
@@ -143,7 +189,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 }  // namespace
 
 extern "C" size_t gcl_graphnorm_ws_bytes(int32_t B, int32_t n, int32_t F) {
-  const size_t parts = (size_t)B * kGnChunks * 2 * sizeof(double);
+  const size_t parts = (size_t)B * (kGnChunks + 1) * 2 * sizeof(double);  // chunk partials + per-sample sums
   const size_t nblk = (size_t)gcl::cdiv(n, 256);
   const size_t cparts = (size_t)B * nblk * 2 * (size_t)F * sizeof(float);
   return parts + cparts + 64;
@@ -157,10 +203,18 @@ extern "C" int gcl_graphnorm_fwd(const float* x, int64_t ldx, int64_t bsx, const
   GCL_CHECK_ARG(ws && ws_bytes >= gcl_graphnorm_ws_bytes(B, n, F) && gcl::aligned16(ws), "graphnorm_fwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   double* part = (double*)ws;
-  hipLaunchKernelGGL((gn_partial_kernel<0>), dim3(kGnChunks, B), dim3(256), 0, st, x, ldx, bsx, nullptr, 0, 0, nullptr,
-                     nullptr, part, n, F);
+  double* fin = part + (size_t)B * kGnChunks * 2;
+  const int nch = gn_chunks(n, F);
+  const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (bsx % 4 == 0) && gcl::aligned16(x);
+  if (vec)
+    hipLaunchKernelGGL((gn_partial_kernel<0, true>), dim3(nch, B), dim3(256), 0, st, x, ldx, bsx, nullptr, 0, 0,
+                       nullptr, nullptr, part, n, F);
+  else
+    hipLaunchKernelGGL((gn_partial_kernel<0, false>), dim3(nch, B), dim3(256), 0, st, x, ldx, bsx, nullptr, 0, 0,
+                       nullptr, nullptr, part, n, F);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, part, fin, nch);
   const unsigned nb = (unsigned)std::min<int64_t>(gcl::cdiv((int64_t)n * F, 256), 1024);
-  hipLaunchKernelGGL(gn_fwd_apply_kernel, dim3(nb, B), dim3(256), 0, st, x, ldx, bsx, gamma, beta, eps, part, y, ldy,
+  hipLaunchKernelGGL(gn_fwd_apply_kernel, dim3(nb, B), dim3(256), 0, st, x, ldx, bsx, gamma, beta, eps, fin, y, ldy,
                      bsy, stats, n, F);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
@@ -175,13 +229,22 @@ extern "C" int gcl_graphnorm_bwd(const float* dy, int64_t lddy, int64_t bsdy, co
   GCL_CHECK_ARG(ws && ws_bytes >= gcl_graphnorm_ws_bytes(B, n, F) && gcl::aligned16(ws), "graphnorm_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   double* part = (double*)ws;
-  float* cpart = (float*)(part + (size_t)B * kGnChunks * 2);
-  hipLaunchKernelGGL((gn_partial_kernel<1>), dim3(kGnChunks, B), dim3(256), 0, st, x, ldx, bsx, dy, lddy, bsdy, gamma,
-                     stats, part, n, F);
+  double* fin = part + (size_t)B * kGnChunks * 2;
+  const int nch = gn_chunks(n, F);
+  float* cpart = (float*)(fin + (size_t)B * 2);
+  const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (bsx % 4 == 0) && (lddy % 4 == 0) && (bsdy % 4 == 0) &&
+                   gcl::aligned16(x) && gcl::aligned16(dy) && gcl::aligned16(gamma);
+  if (vec)
+    hipLaunchKernelGGL((gn_partial_kernel<1, true>), dim3(nch, B), dim3(256), 0, st, x, ldx, bsx, dy, lddy, bsdy,
+                       gamma, stats, part, n, F);
+  else
+    hipLaunchKernelGGL((gn_partial_kernel<1, false>), dim3(nch, B), dim3(256), 0, st, x, ldx, bsx, dy, lddy, bsdy,
+                       gamma, stats, part, n, F);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, part, fin, nch);
   const int rows_per_block = 256;
   const unsigned nblk = (unsigned)gcl::cdiv(n, rows_per_block);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nblk, B), dim3(256), 2 * (size_t)F * (256 / F) * sizeof(float), st, dy, lddy, bsdy, x,
-                     ldx, bsx, gamma, stats, eps, part, dx, lddx, bsdx, cpart, n, F, rows_per_block);
+                     ldx, bsx, gamma, stats, eps, fin, dx, lddx, bsdx, cpart, n, F, rows_per_block);
   GCL_CHECK_LAUNCH();
   const int nparts = (int)(nblk * B);
   int rc = gcl::launch_reduce_parts(cpart, nparts, 2 * F, 2 * F, dgamma, F, 1, F, accumulate, st);

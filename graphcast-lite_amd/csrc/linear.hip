@@ -1058,12 +1058,12 @@ int launch_linear(const float* X, int64_t ldx, const float* in_slope, const floa
 // does the resident-panel kernel take this shape?
 // K: contraction length, N: output width.  Measured on MI355X (tools/gemm_bench.py): the 128x128
 // tile kernel wins once the contraction is long or the output fills its 128 columns.
-bool panel_fits(int K, int N, bool vec_x, bool trans) {
+bool panel_fits(int K, int N, bool vec_x, bool trans, bool w_ok) {
   static const int impl = [] {
     const char* e = getenv("GCL_DENSE_IMPL");
     return !e ? 0 : strcmp(e, "tile") == 0 ? 1 : strcmp(e, "panel") == 0 ? 2 : 0;
   }();
-  const bool tile_ok = vec_x && K % 4 == 0 && N % 4 == 0;
+  const bool tile_ok = vec_x && w_ok && K % 4 == 0 && N % 4 == 0;
   if (impl == 1 && tile_ok) return false;
   if (impl == 0 && tile_ok && (K > 128 || (N >= 128 && (K >= 128 || trans)))) return false;
   if (K < 1 || K > 256 || N < 1 || N > 256) return false;
@@ -1120,7 +1120,7 @@ extern "C" int gcl_dense_fwd(const float* x, int64_t ldx, int32_t act, const flo
                 (long long)ldy, (long long)ldw);
   if (int rc = check_act("dense_fwd", act, slope)) return rc;
   const bool vec_x = (Fin % 4 == 0) && (ldx % 4 == 0) && gcl::aligned16(x);
-  if (!addend && ldw == Fin && (use_valu() || panel_fits(Fin, Fout, vec_x, false)))
+  if (!addend && ldw == Fin && (use_valu() || panel_fits(Fin, Fout, vec_x, false, (ldw % 4 == 0) && gcl::aligned16(W))))
     return launch_linear<EPI_BIAS>(x, ldx, act == GCL_ACT_PRELU ? slope : nullptr, W, Fin, 0, bias, y, ldy, rows, Fin,
                                    Fout, nullptr, 0, nullptr, nullptr, nullptr, (hipStream_t)stream, act);
   return launch_gemm<EPI_BIAS>(x, ldx, act, act == GCL_ACT_PRELU ? slope : nullptr, W, ldw, 0, bias, y, ldy, rows, Fin,
@@ -1170,7 +1170,7 @@ extern "C" int gcl_dense_bwd_dx(const float* dy, int64_t lddy, const float* W, i
   const float* zz = act == GCL_ACT_NONE ? nullptr : z;
   const bool vec_x = (Fout % 4 == 0) && (lddy % 4 == 0) && gcl::aligned16(dy);
   // contraction over Fout: "weights" are W^T, i.e. Wl[j=c][k=o] = W[o*ldw + c]
-  if (!addend && ldw == Fin && (use_valu() || panel_fits(Fout, Fin, vec_x, true)))
+  if (!addend && ldw == Fin && (use_valu() || panel_fits(Fout, Fin, vec_x, true, (ldw % 4 == 0) && gcl::aligned16(W))))
     rc = launch_linear<EPI_DX>(dy, lddy, nullptr, W, Fin, 1, nullptr, dx, lddx, rows, Fout, Fin, zz, ldz, sl, slope_part,
                                &nparts, st, act);
   else
@@ -1200,15 +1200,18 @@ static int dw_block(const float* dy, int64_t lddy, const float* x, int64_t ldx, 
   int NO = (Fout + 31) / 32;
   NO = NO <= 2 ? NO : NO <= 4 ? 4 : 8;  // instantiated: 1, 2, 4, 8 (extra slabs are zero)
   const int FinP = NC * 32, FoutP = NO * 32;
+  const size_t lds = (size_t)kDwRT * (FoutP + FinP) * sizeof(float);
+  // one partial tile per block: no more blocks than are resident at once (wide tiles fill the LDS
+  // with one block per CU, and their partials are what the reduction then has to read back)
+  const int64_t cap = lds > 80 * 1024 ? gcl::kNumCU : kDwBlocks;
   int64_t nblk = gcl::cdiv(rows, 2 * kDwRT);  // at least two steps per block
-  if (nblk > kDwBlocks) nblk = kDwBlocks;
+  if (nblk > cap) nblk = cap;
   if (nblk < 1) nblk = 1;
   int64_t rpb = gcl::cdiv(rows, nblk);
   rpb = gcl::cdiv(rpb, kDwRT) * kDwRT;
   nblk = rows > 0 ? gcl::cdiv(rows, rpb) : 1;
   float* part = (float*)ws;
   float* dbpart = part + (size_t)kDwBlocks * FoutP * FinP;
-  const size_t lds = (size_t)kDwRT * (FoutP + FinP) * sizeof(float);
   const bool vec = (lddy % 4 == 0) && (ldx % 4 == 0) && gcl::aligned16(dy) && gcl::aligned16(x);
 #define GCL_DW3(NO_, NC_, V_)                                                                                     \
   do {                                                                                                            \

@@ -204,16 +204,19 @@ class FlatParams:
             pos += 1
         self.num_module_params = pos
         dev = self.params[0].device
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
+        # every parameter starts on a 256-byte boundary (the dense kernels read weight rows as
+        # 16-byte vectors); the padding stays zero in the weights, the gradients and Adam's moments
+        self.offsets, total = [], 0
         for p in self.params:
+            self.offsets.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, off in zip(self.params, self.offsets):
             k = p.numel()
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view(p.shape)
             p.grad = self.grad[off:off + k].view(p.shape)
-            off += k
         self.numel = total
 
     def zero_grad(self):
@@ -266,13 +269,12 @@ class FusedAdam:
         """The dictionary `torch.optim.Adam(model.parameters()).state_dict()` would hold after the
         same steps (per-parameter `step / exp_avg / exp_avg_sq`), so `save_checkpoint` files written
         from the fused optimiser resume under the reference's `load_checkpoint` (src/train.py:37-49)."""
-        t, state, off = self.t, {}, 0
-        for p, i in zip(self.flat.params, self.flat.index):
+        t, state = self.t, {}
+        for p, i, off in zip(self.flat.params, self.flat.index, self.flat.offsets):
             k = p.numel()
             if t > 0:
                 state[i] = {"step": torch.tensor(float(t)), "exp_avg": self.m[off:off + k].view(p.shape).clone(),
                             "exp_avg_sq": self.v[off:off + k].view(p.shape).clone()}
-            off += k
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                  "decoupled_weight_decay": False, "params": list(range(self.flat.num_module_params))}
@@ -285,9 +287,9 @@ class FusedAdam:
             raise ValueError("FusedAdam implements plain Adam only (amsgrad / maximize are not supported)")
         self.lr, self.betas, self.eps = group["lr"], tuple(group["betas"]), group["eps"]
         self.wd = group.get("weight_decay", 0.0)
-        steps, off = set(), 0
+        steps = set()
         self.m.zero_(), self.v.zero_()
-        for p, i in zip(self.flat.params, self.flat.index):
+        for p, i, off in zip(self.flat.params, self.flat.index, self.flat.offsets):
             k = p.numel()
             st = sd["state"].get(i, sd["state"].get(str(i)))
             if st is not None:
@@ -296,7 +298,6 @@ class FusedAdam:
                 self.m[off:off + k].copy_(st["exp_avg"].reshape(-1))
                 self.v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
                 steps.add(int(float(st["step"])))
-            off += k
         if len(steps) > 1:
             raise ValueError(f"FusedAdam keeps one step counter; the state holds several: {sorted(steps)}")
         self.step_dev.fill_(steps.pop() if steps else 0)
