@@ -217,7 +217,8 @@ class FlatParams:
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view(p.shape)
             p.grad = self.grad[off:off + k].view(p.shape)
-        self.numel = total
+        self.numel = total  # bucket length (with alignment padding)
+        self.num_params = sum(p.numel() for p in self.params)
 
     def zero_grad(self):
         self.grad.zero_()

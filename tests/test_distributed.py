@@ -69,7 +69,8 @@ def test_two_rank_gradient_equals_global_batch(tmp_path):
     got = torch.load(os.path.join(tmp_path, "dp.pt"))
     m, X, y = _make()
     flat = FlatParams(m)
-    assert flat.numel == got["numel"] == 53784  # baseline parameter count, shared PReLU counted once
+    assert flat.numel == got["numel"] and flat.numel % 64 == 0  # bucket length: every parameter padded to 256 B
+    assert flat.num_params == 53784  # baseline parameter count, shared PReLU counted once
     flat.zero_grad()
     T.train_step_loss(m, X, y, lat_weights=T.get_lat_weights(32, 64)).backward()
     rel = ((got["grad"] - flat.grad).norm() / flat.grad.norm()).item()
