@@ -8,7 +8,9 @@
 //   K is walked in chunks of 32 through a double-buffered LDS stage ([128][34] + [128][34] floats
 //   per buffer = 68 KiB for both: two blocks per CU, two waves per SIMD);
 //   the global loads of chunk c+1 are issued before the 64 MFMAs of chunk c and committed to the
-//   other buffer after them: one barrier per chunk;
+//   other buffer after them: one barrier per chunk; blocks are persistent and the first chunk of
+//   the NEXT tile is fetched under the last chunk of the current one, so only the first tile of a
+//   block pays the load latency;
 //   fragments are 8-byte LDS reads (two k-steps each) at row stride 34 (stride/2 odd: conflict-free).
 // Tiles are dealt XCD-aware: the column tiles of one row tile get consecutive slots of the SAME
 // XCD, so the second read of an X tile hits that XCD's L2.
@@ -31,20 +33,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(
   extern __shared__ __align__(16) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t L = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (L >= total) {  // block-uniform
+  // persistent over the tiles of this block's XCD: slot, slot + nslots, ...
+  const int xcd = blockIdx.x & 7, nslots = gridDim.x >> 3;
+  const int64_t Lbase = (int64_t)xcd * per_xcd;
+  const int64_t Lend = (Lbase + per_xcd) < total ? (Lbase + per_xcd) : total;
+  int64_t L = Lbase + (blockIdx.x >> 3);
+  double slope_acc = 0.0;
+  if (L >= Lend) {  // block-uniform
     if (EPI == EPI_DX && slope_part && tid == 0) slope_part[blockIdx.x] = 0.0;
     return;
   }
-  const int64_t r0 = (L / nt) * TM;
-  const int n0 = (int)(L % nt) * TN;
   const float slope = in_slope ? *in_slope : 1.f;
   const bool xact = EPI == EPI_BIAS && akind != gcl::kActNone;
   const bool silu = akind == gcl::kActSilu;
+  const bool has_z = EPI == EPI_DX && Z != nullptr;
+  const bool has_add = add != nullptr;
 
   float4 pre[8];  // [0..3] X, [4..7] W of the next chunk
   const float4* zero = gcl_zero4;
-  auto issue = [&](int k0) {
+  auto issue = [&](int64_t r0, int n0, int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + 256 * i;
@@ -102,84 +109,104 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(
     }
   };
 
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const int nchunks = (K + KC - 1) / KC;
-  issue(0);
+  int64_t r0 = (L / nt) * TM;
+  int n0 = (int)(L % nt) * TN;
+  int sel = 0;
+  issue(r0, n0, 0);
   commit(smem);
   __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
-    float* buf = smem + (size_t)(c & 1) * (TM + TN) * KP;
-    if (c + 1 < nchunks) issue((c + 1) * KC);  // block-uniform
-    const float* ap = buf + (wm * 64 + (lane & 31)) * KP + 2 * (lane >> 5);
-    const float* bp = buf + TM * KP + (wn * 64 + (lane & 31)) * KP + 2 * (lane >> 5);
-#pragma unroll
-    for (int q = 0; q < KC / 4; ++q) {
-      const float2 a0 = *reinterpret_cast<const float2*>(ap + 4 * q);
-      const float2 a1 = *reinterpret_cast<const float2*>(ap + 32 * KP + 4 * q);
-      const float2 b0 = *reinterpret_cast<const float2*>(bp + 4 * q);
-      const float2 b1 = *reinterpret_cast<const float2*>(bp + 32 * KP + 4 * q);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[1][1], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[1][1], 0, 0, 0);
-    }
-    if (c + 1 < nchunks) commit(smem + (size_t)((c + 1) & 1) * (TM + TN) * KP);
-    __syncthreads();
-  }
+  for (;;) {
+    const int64_t Ln = L + nslots;
+    const bool more = Ln < Lend;  // block-uniform
+    const int64_t nr0 = more ? (Ln / nt) * TM : 0;
+    const int nn0 = more ? (int)(Ln % nt) * TN : 0;
 
-  // epilogue: lane owns column j and 16 rows of each of its 4 MFMA tiles; branch-free accesses
-  const int64_t nr = (rows - r0) < TM ? (rows - r0) : TM;
-  const int ncols = (N - n0) < TN ? (N - n0) : TN;
-  const bool has_z = EPI == EPI_DX && Z != nullptr;
-  const bool has_add = add != nullptr;
-  const __amdgpu_buffer_rsrc_t ry = make_rsrc(Y + r0 * ldy + n0, win_bytes(nr, ldy, ncols));
-  const __amdgpu_buffer_rsrc_t rz = make_rsrc(has_z ? Z + r0 * ldz + n0 : Y, has_z ? win_bytes(nr, ldz, ncols) : 0);
-  const __amdgpu_buffer_rsrc_t ra = make_rsrc(has_add ? add + r0 * ldadd + n0 : Y, has_add ? win_bytes(nr, ldadd, ncols) : 0);
-  double slope_acc = 0.0;
+    f32x16 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = wn * 64 + j * 32 + (lane & 31);
-      const bool jok = col < ncols;
-      const float bj = (EPI == EPI_BIAS && bias && jok) ? bias[n0 + col] : 0.f;
-      float zv[16], av[16];
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = wm * 64 + i * 32 + d_row(r, lane);
-        zv[r] = buf_ld1(rz, jok ? (unsigned)((rr * ldz + col) * 4) : kOOB);    // 0 when absent
-        av[r] = buf_ld1(ra, jok ? (unsigned)((rr * ldadd + col) * 4) : kOOB);  // 0 when absent
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int c = 0; c < nchunks; ++c) {
+      float* buf = smem + (size_t)sel * (TM + TN) * KP;
+      const bool lastc = c + 1 == nchunks;
+      // the next chunk - of this tile or the first of the next tile - is in flight under the MFMAs
+      if (!lastc) issue(r0, n0, (c + 1) * KC);
+      else if (more) issue(nr0, nn0, 0);
+      const float* ap = buf + (wm * 64 + (lane & 31)) * KP + 2 * (lane >> 5);
+      const float* bp = buf + TM * KP + (wn * 64 + (lane & 31)) * KP + 2 * (lane >> 5);
+#pragma unroll
+      for (int q = 0; q < KC / 4; ++q) {
+        const float2 a0 = *reinterpret_cast<const float2*>(ap + 4 * q);
+        const float2 a1 = *reinterpret_cast<const float2*>(ap + 32 * KP + 4 * q);
+        const float2 b0 = *reinterpret_cast<const float2*>(bp + 4 * q);
+        const float2 b1 = *reinterpret_cast<const float2*>(bp + 32 * KP + 4 * q);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[1][1], 0, 0, 0);
       }
+      if (!lastc || more) commit(smem + (size_t)(sel ^ 1) * (TM + TN) * KP);
+      __syncthreads();
+      sel ^= 1;
+    }
+
+    // epilogue: lane owns column j and 16 rows of each of its 4 MFMA tiles; branch-free accesses.
+    // The store / load offsets are the same for every tile: an opaque copy of the lane id keeps
+    // the compiler from hoisting ~200 registers of them out of the persistent loop.
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int64_t nr = (rows - r0) < TM ? (rows - r0) : TM;
+    const int ncols = (N - n0) < TN ? (N - n0) : TN;
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(Y + r0 * ldy + n0, win_bytes(nr, ldy, ncols));
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(has_z ? Z + r0 * ldz + n0 : Y, has_z ? win_bytes(nr, ldz, ncols) : 0);
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(has_add ? add + r0 * ldadd + n0 : Y, has_add ? win_bytes(nr, ldadd, ncols) : 0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = wm * 64 + i * 32 + d_row(r, lane);
-        float v = acc[i][j][r];
-        if (EPI == EPI_DX) {
-          if (silu) {  // block-uniform
-            v *= has_z ? gcl::dsilu_f(zv[r]) : 1.f;
-          } else {
-            const bool neg = has_z && (zv[r] <= 0.f);
-            slope_acc += neg ? (double)(v * zv[r]) : 0.0;
-            v = neg ? v * slope : v;
-          }
-        } else {
-          v += bj;
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = wn * 64 + j * 32 + (lane_e & 31);
+        const bool jok = col < ncols;
+        const float bj = (EPI == EPI_BIAS && bias && jok) ? bias[n0 + col] : 0.f;
+        float zv[16], av[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = wm * 64 + i * 32 + d_row(r, lane_e);
+          zv[r] = buf_ld1(rz, jok ? (unsigned)((rr * ldz + col) * 4) : kOOB);    // 0 when absent
+          av[r] = buf_ld1(ra, jok ? (unsigned)((rr * ldadd + col) * 4) : kOOB);  // 0 when absent
         }
-        v += av[r];
-        buf_st1(ry, jok ? (unsigned)((rr * ldy + col) * 4) : kOOB, v);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = wm * 64 + i * 32 + d_row(r, lane_e);
+          float v = acc[i][j][r];
+          if (EPI == EPI_DX) {
+            if (silu) {  // block-uniform
+              v *= has_z ? gcl::dsilu_f(zv[r]) : 1.f;
+            } else {
+              const bool neg = has_z && (zv[r] <= 0.f);
+              slope_acc += neg ? (double)(v * zv[r]) : 0.0;
+              v = neg ? v * slope : v;
+            }
+          } else {
+            v += bj;
+          }
+          v += av[r];
+          buf_st1(ry, jok ? (unsigned)((rr * ldy + col) * 4) : kOOB, v);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the four slabs' Z / addend loads from piling up in registers
       }
     }
+    if (!more) break;
+    L = Ln;
+    r0 = nr0;
+    n0 = nn0;
   }
   if (EPI == EPI_DX && slope_part) {
     for (int off = 32; off > 0; off >>= 1) slope_acc += __shfl_down(slope_acc, off, 64);
@@ -203,6 +230,8 @@ static inline GtGeom gt_geom(int64_t rows, int N) {
   // whole row tiles per XCD so that the column tiles of a row tile share an L2
   const int64_t row_tiles_per_xcd = gcl::cdiv(gcl::cdiv(rows, kGtTM), gcl::kNumXCD);
   g.per_xcd = (int)(row_tiles_per_xcd * g.nt);
-  g.grid = (unsigned)(g.per_xcd * gcl::kNumXCD);
+  // persistent: two resident blocks per CU (LDS-limited), i.e. 64 slots per XCD
+  const int slots = g.per_xcd < 2 * gcl::kNumCU / gcl::kNumXCD ? g.per_xcd : 2 * gcl::kNumCU / gcl::kNumXCD;
+  g.grid = (unsigned)(slots * gcl::kNumXCD);
   return g;
 }

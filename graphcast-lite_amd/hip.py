@@ -244,6 +244,12 @@ def linear_bwd_dw(dy, x, in_slope, dW, db, accumulate: bool, act=None):
 ACT_NONE, ACT_PRELU, ACT_SILU = 0, 1, 2
 
 
+# bench.py sets this to {"rows": r, "Fin": k, "Fout": n, "events": []} to time the dense launches of
+# that shape (the edge-MLP contractions of the InteractionNet processor) with HIP events recorded on
+# the launch stream.
+DENSE_PROFILE = None
+
+
 def dense_fwd(x, W, bias, act=ACT_NONE, slope=None, addend=None, out=None):
     """y = act(x) W^T + bias + addend.  x / W / addend / out may be column blocks (unit channel
     stride, any row stride) of wider tensors."""
@@ -252,8 +258,16 @@ def dense_fwd(x, W, bias, act=ACT_NONE, slope=None, addend=None, out=None):
     assert W.shape[1] == Fin and W.stride(1) == 1 and x.stride(1) == 1
     if out is None:
         out = torch.empty(rows, Fout, dtype=torch.float32, device=x.device)
+    prof = DENSE_PROFILE
+    prof = prof is not None and prof["rows"] == rows and prof["Fin"] == Fin and prof["Fout"] == Fout
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _check(lib().gcl_dense_fwd(_p(x), _ld(x), int(act), _p(slope), _p(W), W.stride(0), _p(bias), _p(addend),
                                _ld(addend) if addend is not None else 0, _p(out), _ld(out), rows, Fin, Fout, _stream()))
+    if prof:
+        e1.record()
+        DENSE_PROFILE["events"].append((e0, e1))
     return out
 
 
