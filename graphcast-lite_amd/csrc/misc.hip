@@ -207,6 +207,38 @@ __global__ __launch_bounds__(256) void ar_advance_kernel(const float* __restrict
   }
 }
 
+// Input windows from a device-resident fp16 time series (src/data/dataloader_chunked.py:179-223):
+//   X[b, g, o*C + c] = (float(series[t0[b] + o,        lon, lat, c]) - mean[c]) / std[c]
+//   Y[b, g, p*C + c] = (float(series[t0[b] + obs + p,  lon, lat, c]) - mean[c]) / std[c]
+// with g = lat * n_lon + lon (lat-major, lon fastest - the node order of the graphs) and only the
+// first C of the Ct stored channels used.  fp16 -> fp32 is exact and the subtraction / IEEE
+// division are the reference's numpy operations, so the result is bit-identical to the loader's.
+// One thread per output element: writes are fully coalesced, reads are C-channel runs.
+__global__ __launch_bounds__(256) void window_pack_kernel(const _Float16* __restrict__ series, int64_t T, int32_t n_lon,
+                                                          int32_t n_lat, int32_t Ct, const int64_t* __restrict__ t0,
+                                                          const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                          int32_t C, int32_t first, int32_t frames,
+                                                          float* __restrict__ out, int32_t B) {
+  const int64_t G = (int64_t)n_lon * n_lat;
+  const int64_t row = (int64_t)frames * C;
+  const int64_t total = (int64_t)B * G * row;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int k = (int)(idx % row);
+    const int64_t bg = idx / row;
+    const int64_t g = bg % G;
+    const int b = (int)(bg / G);
+    const int f = k / C, c = k - f * C;
+    const int lat = (int)(g / n_lon), lon = (int)(g - (int64_t)lat * n_lon);
+    const int64_t t = t0[b] + first + f;
+    float v = __builtin_nanf("");  // a window that leaves the series is an error made visible
+    if (t >= 0 && t < T) {
+      const float x = (float)series[(((int64_t)t * n_lon + lon) * n_lat + lat) * Ct + c];
+      v = (x - mean[c]) / stdv[c];
+    }
+    out[idx] = v;
+  }
+}
+
 inline unsigned grid_for(int64_t total, int cap = 4096) {
   int64_t nb = gcl::cdiv(total > 0 ? total : 1, 256);
   return (unsigned)(nb > cap ? cap : nb);
@@ -318,6 +350,24 @@ extern "C" int gcl_ar_advance(const float* state, const float* delta, const floa
   const int64_t total = (int64_t)B * G * obs * C;
   hipLaunchKernelGGL(ar_advance_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, state, delta,
                      y_step, ldy, bsy, chan_kind, new_state, out, ldo, bso, out_off, B, G, obs, C, residual);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+extern "C" int gcl_window_pack(const uint16_t* series, int64_t T, int32_t n_lon, int32_t n_lat, int32_t Ct,
+                               const int64_t* t0, const float* mean, const float* stdv, int32_t C, int32_t obs,
+                               int32_t pred, float* X, float* Y, int32_t B, gcl_stream_t stream) {
+  GCL_CHECK_ARG(series && t0 && mean && stdv && X, "window_pack: null argument");
+  GCL_CHECK_ARG(T > 0 && n_lon > 0 && n_lat > 0 && Ct > 0 && C > 0 && C <= Ct && obs > 0 && pred >= 0 && B > 0,
+                "window_pack: bad shape (T=%lld grid %dx%d C=%d of %d obs=%d pred=%d)", (long long)T, n_lon, n_lat, C, Ct,
+                obs, pred);
+  GCL_CHECK_ARG(pred == 0 || Y, "window_pack: pred > 0 needs the Y buffer");
+  const int64_t G = (int64_t)n_lon * n_lat;
+  hipLaunchKernelGGL(window_pack_kernel, dim3(grid_for((int64_t)B * G * obs * C, 16384)), dim3(256), 0,
+                     (hipStream_t)stream, (const _Float16*)series, T, n_lon, n_lat, Ct, t0, mean, stdv, C, 0, obs, X, B);
+  if (pred > 0)
+    hipLaunchKernelGGL(window_pack_kernel, dim3(grid_for((int64_t)B * G * pred * C, 16384)), dim3(256), 0,
+                       (hipStream_t)stream, (const _Float16*)series, T, n_lon, n_lat, Ct, t0, mean, stdv, C, obs, pred, Y, B);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

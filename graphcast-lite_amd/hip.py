@@ -73,6 +73,7 @@ _SIGNATURES = {
     "gcl_act_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "gcl_act_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, C.c_size_t, _vp]),
     "gcl_act_bwd_ws_bytes": (C.c_size_t, []),
+    "gcl_window_pack": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "gcl_ar_advance": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32,
                                  _i32, _vp]),
     "gcl_gather2_rows": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
@@ -552,3 +553,21 @@ def act_bwd(x, dy, act, slope=None, d_slope=None):
     _check(lib().gcl_act_bwd(_p(x), _p(dy), _p(dx), x.numel(), int(act), _p(slope), _p(d_slope), ws.data_ptr(), ws.numel(),
                              _stream()))
     return dx
+
+
+def window_pack(series, t0, mean, std, C: int, obs: int, pred: int):
+    """series: fp16 [T, n_lon, n_lat, Ct] (or flat [T, N, Ct]) on the GPU; t0: int64 [B] window starts on
+    the GPU.  Returns X [B, G, obs*C] and Y [B, G, pred*C] (None when pred == 0)."""
+    assert series.is_cuda and series.dtype == torch.float16 and series.is_contiguous()
+    assert t0.is_cuda and t0.dtype == torch.int64 and t0.is_contiguous()
+    if series.dim() == 3:
+        T, n_lon, Ct = series.shape
+        n_lat = 1
+    else:
+        T, n_lon, n_lat, Ct = series.shape
+    B, G = t0.numel(), n_lon * n_lat
+    X = torch.empty(B, G, obs * C, dtype=torch.float32, device=series.device)
+    Y = torch.empty(B, G, pred * C, dtype=torch.float32, device=series.device) if pred > 0 else None
+    _check(lib().gcl_window_pack(series.data_ptr(), T, n_lon, n_lat, Ct, t0.data_ptr(), _p(mean), _p(std), C, obs, pred,
+                                 _p(X), _p(Y), B, _stream()))
+    return X, Y

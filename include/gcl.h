@@ -281,6 +281,16 @@ int gcl_act_bwd(const float* x, const float* dy, float* dx, int64_t count, int32
                 const float* slope, float* d_slope, void* ws, size_t ws_bytes, gcl_stream_t stream);
 size_t gcl_act_bwd_ws_bytes(void);
 
+/* Input windows from a device-resident fp16 time series - the reference's on-the-fly loader
+ * (src/data/dataloader_chunked.py:179-223: fp16 memmap (T, lon, lat, Ct) -> first C channels ->
+ * fp32 -> (x - mean) / std -> (lat, lon)-major transpose -> [G, obs*C] / [G, pred*C]), batched over
+ * B window starts t0[b] (device int64).  n_lat = 1, n_lon = N reads the flat (T, N, Ct) layout
+ * (:184-197).  Bit-identical to the numpy loader; frames outside [0, T) come back as NaN. */
+int gcl_window_pack(const uint16_t* series /* IEEE binary16 */, int64_t T, int32_t n_lon, int32_t n_lat,
+                    int32_t Ct, const int64_t* t0, const float* mean, const float* stdv, int32_t C,
+                    int32_t obs, int32_t pred, float* X /*[B,G,obs*C]*/, float* Y /*[B,G,pred*C] or NULL*/,
+                    int32_t B, gcl_stream_t stream);
+
 /* One autoregressive advance of the observation window, fused (scripts/predict.py:512-535 and the
  * same steps in src/train.py:203-228): step_out = residual ? x_last + delta : delta; static channels
  * (chan_kind 1) carry x_last forward, forcing channels (chan_kind 2) take y_step when it is given;

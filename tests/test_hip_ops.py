@@ -441,3 +441,35 @@ def test_act_fwd_bwd(hip, act):
     assert rel(hip.act_bwd(xd, dy.float().to(DEV), act, ad, ds), x.grad) < 1e-6
     if act == 1:
         assert abs(ds.item() - a.grad.item()) < 1e-4 * abs(a.grad.item())
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_window_pack_matches_loader_bit_for_bit(hip, flat, tmp_path):
+    """gcl_window_pack / data.TimeseriesChunkDataset against the numpy restatement of the reference's
+    __getitem__ (src/data/dataloader_chunked.py:179-223): bit-identical, both on-disk layouts."""
+    import json
+    from graphcast_lite_amd.data import TimeseriesChunkDataset
+    from oracle.data import window_sample
+
+    rng = np.random.default_rng(7)
+    T, n_lon, n_lat, Ct, C, obs, pred = 9, 12, 7, 5, 4, 2, 3
+    shape = (T, n_lon * n_lat, Ct) if flat else (T, n_lon, n_lat, Ct)
+    series = (rng.standard_normal(shape) * 30).astype(np.float16)
+    series.tofile(tmp_path / "data.npy")  # raw memmap, no header
+    info = {"n_time": T, "n_feat": Ct, "flat": flat}
+    info.update({"n_nodes": n_lon * n_lat} if flat else {"n_lon": n_lon, "n_lat": n_lat})
+    (tmp_path / "dataset_info.json").write_text(json.dumps(info))
+    mean, std = rng.standard_normal(Ct).astype(np.float64), (rng.random(Ct) + 0.5).astype(np.float64)
+    np.savez(tmp_path / "scalers.npz", mean=mean, std=std, n=T)
+    ds = TimeseriesChunkDataset(str(tmp_path), obs_window=obs, pred_steps=pred, split="all", n_features=C, device=DEV)
+    assert len(ds) == T - obs - pred + 1
+    X, Y = ds.batch([3, 0, 4])
+    for k, t in enumerate([3, 0, 4]):
+        Xr, Yr = window_sample(series, t, obs, pred, C, mean.astype(np.float32)[:C], std.astype(np.float32)[:C], flat)
+        assert np.array_equal(X[k].cpu().numpy(), Xr) and np.array_equal(Y[k].cpu().numpy(), Yr)
+    x1, y1 = ds[2]
+    assert torch.equal(x1, ds.batch([2])[0][0]) and x1.shape == (n_lon * n_lat, obs * C)
+    # a window that leaves the series is flagged, not read
+    t0 = torch.tensor([T - 2], dtype=torch.int64, device=DEV)
+    Xo, Yo = hip.window_pack(ds.chunks[0], t0, ds.mean, ds.std, C, obs, pred)
+    assert not torch.isnan(Xo).any() and torch.isnan(Yo).all()

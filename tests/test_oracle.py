@@ -265,3 +265,36 @@ def test_interaction_net_processor_batched_equals_per_sample():
     yb = proc(x, ei, raw)
     for b in range(2):
         assert torch.allclose(yb[b], proc(x[b], ei, raw), atol=1e-6)
+
+
+def test_window_sample_hand_case_and_split_indices():
+    """oracle.data.window_sample (src/data/dataloader_chunked.py:179-223) on a 2x3 grid by hand, and the
+    host-side sample index / split logic of the product (:132-172)."""
+    from oracle.data import window_sample
+    from graphcast_lite_amd.data import sample_indices
+
+    T, n_lon, n_lat, Ct, C = 4, 2, 3, 3, 2
+    chunk = np.arange(T * n_lon * n_lat * Ct, dtype=np.float16).reshape(T, n_lon, n_lat, Ct)
+    mean, std = np.array([1.0, 2.0], np.float32), np.array([2.0, 4.0], np.float32)
+    X, Y = window_sample(chunk, 1, 2, 1, C, mean, std, flat=False)
+    assert X.shape == (6, 4) and Y.shape == (6, 2) and X.dtype == np.float32
+    for lat in range(n_lat):
+        for lon in range(n_lon):
+            g = lat * n_lon + lon  # lat-major, lon fastest: the node order of np.meshgrid(lons, lats)
+            for o in range(2):
+                for c in range(C):
+                    assert X[g, o * C + c] == (np.float32(chunk[1 + o, lon, lat, c]) - mean[c]) / std[c]
+            assert Y[g, 1] == (np.float32(chunk[3, lon, lat, 1]) - mean[1]) / std[1]
+    Xf, Yf = window_sample(chunk.reshape(T, 6, Ct), 0, 1, 2, C, mean, std, flat=True)
+    assert Xf.shape == (6, 2) and Yf.shape == (6, 4) and Yf[5, 3] == (np.float32(chunk.reshape(T, 6, Ct)[2, 5, 1]) - 2) / 4
+
+    # two chunks of 10 and 4 frames, window 3: 8 + 2 samples, never across the boundary
+    allidx = sample_indices([10, 4], 2, 1, "all", 0.2)
+    assert allidx == [(0, t) for t in range(8)] + [(1, 0), (1, 1)]
+    assert sample_indices([10, 4], 2, 1, "train", 0.2) == allidx[:8]
+    assert sample_indices([10, 4], 2, 1, "test", 0.2) == allidx[8:]
+    assert sample_indices([10, 4], 2, 1, "val", 0.2) == allidx[8:9]
+    assert sample_indices([10, 4], 2, 1, "test_only", 0.2) == allidx[9:]
+    assert sample_indices([2], 2, 1, "all", 0.2) == []
+    with pytest.raises(ValueError):
+        sample_indices([10], 2, 1, "nope", 0.2)
