@@ -17,19 +17,22 @@
 // Included by linear.hip (same translation unit: shares its helpers and launch plumbing).
 #pragma once
 
-constexpr int kGtTM = 128, kGtTN = 128, kGtKC = 32, kGtKP = kGtKC + 2;
-constexpr size_t kGtLds = (size_t)2 * (kGtTM + kGtTN) * kGtKP * sizeof(float);
+constexpr int kGtTN = 128, kGtKC = 32, kGtKP = kGtKC + 2;
+// MI = 32-row MFMA tiles per wave: the block tile is (64*MI) x 128.  MI = 1 (64-row tiles) is used when
+// 128-row tiles would leave the persistent grid a short, badly balanced queue (a few hundred tiles).
+constexpr size_t gt_lds(int MI) { return (size_t)2 * (64 * MI + kGtTN) * kGtKP * sizeof(float); }
 
 // EPI_BIAS: akind/in_slope describe the activation applied to X on load.
 // EPI_DX  : X is dY (no activation), Wl = W^T (TRANS), akind/in_slope describe the activation whose
 //           derivative at Z multiplies the result; slope_part[block] gets the PReLU slope partial.
-template <int EPI, bool TRANS>
-__global__ __launch_bounds__(256, 2) void gemm_tile_kernel(
+template <int EPI, bool TRANS, int MI>
+__global__ __launch_bounds__(256, (MI == 1 ? 3 : 2)) void gemm_tile_kernel(
     const float* __restrict__ X, int64_t ldx, int32_t akind, const float* __restrict__ in_slope,
     const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy,
     int64_t rows, int32_t K, int32_t N, const float* __restrict__ Z, int64_t ldz, const float* __restrict__ add,
     int64_t ldadd, double* __restrict__ slope_part, int32_t nt, int64_t total, int32_t per_xcd) {
-  constexpr int TM = kGtTM, TN = kGtTN, KC = kGtKC, KP = kGtKP;
+  constexpr int TM = 64 * MI, TN = kGtTN, KC = kGtKC, KP = kGtKP;
+  constexpr int NX = 2 * MI;  // float4 loads per thread for the X chunk
   extern __shared__ __align__(16) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -49,11 +52,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(
   const bool has_z = EPI == EPI_DX && Z != nullptr;
   const bool has_add = add != nullptr;
 
-  float4 pre[8];  // [0..3] X, [4..7] W of the next chunk
+  float4 pre[NX + 4];  // [0..NX) X, [NX..NX+4) W of the next chunk
   const float4* zero = gcl_zero4;
   auto issue = [&](int64_t r0, int n0, int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NX; ++i) {
       const int idx = tid + 256 * i;
       const int row = idx >> 3, c4 = idx & 7;
       const bool ok = (r0 + row < rows) && (k0 + 4 * c4 < K);
@@ -67,12 +70,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(
         const int k = idx >> 5, j4 = idx & 31;
         const bool ok = (k0 + k < K) && (n0 + 4 * j4 < N);
         const float4* p = ok ? reinterpret_cast<const float4*>(W + (int64_t)(k0 + k) * ldw + n0 + 4 * j4) : zero;
-        pre[4 + i] = *p;
+        pre[NX + i] = *p;
       } else {
         const int j = idx >> 3, c4 = idx & 7;
         const bool ok = (n0 + j < N) && (k0 + 4 * c4 < K);
         const float4* p = ok ? reinterpret_cast<const float4*>(W + (int64_t)(n0 + j) * ldw + k0 + 4 * c4) : zero;
-        pre[4 + i] = *p;
+        pre[NX + i] = *p;
       }
     }
   };
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(
     float* Xl = buf;
     float* Wl = buf + TM * KP;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NX; ++i) {
       const int idx = tid + 256 * i;
       const int row = idx >> 3, c4 = idx & 7;
       float4 v = pre[i];
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + 256 * i;
-      const float4 v = pre[4 + i];
+      const float4 v = pre[NX + i];
       if (TRANS) {
         const int k = idx >> 5, j4 = idx & 31;
         float* d = Wl + (4 * j4) * KP + k;
@@ -122,9 +125,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(
     const int64_t nr0 = more ? (Ln / nt) * TM : 0;
     const int nn0 = more ? (int)(Ln % nt) * TN : 0;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -136,22 +139,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(
       // the next chunk - of this tile or the first of the next tile - is in flight under the MFMAs
       if (!lastc) issue(r0, n0, (c + 1) * KC);
       else if (more) issue(nr0, nn0, 0);
-      const float* ap = buf + (wm * 64 + (lane & 31)) * KP + 2 * (lane >> 5);
+      const float* ap = buf + (wm * 32 * MI + (lane & 31)) * KP + 2 * (lane >> 5);
       const float* bp = buf + TM * KP + (wn * 64 + (lane & 31)) * KP + 2 * (lane >> 5);
 #pragma unroll
       for (int q = 0; q < KC / 4; ++q) {
-        const float2 a0 = *reinterpret_cast<const float2*>(ap + 4 * q);
-        const float2 a1 = *reinterpret_cast<const float2*>(ap + 32 * KP + 4 * q);
+        float2 a[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const float2*>(ap + i * 32 * KP + 4 * q);
         const float2 b0 = *reinterpret_cast<const float2*>(bp + 4 * q);
         const float2 b1 = *reinterpret_cast<const float2*>(bp + 32 * KP + 4 * q);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[1][1], 0, 0, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[1][1], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b0.x, acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b1.x, acc[i][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b0.y, acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b1.y, acc[i][1], 0, 0, 0);
+        }
       }
       if (!lastc || more) commit(smem + (size_t)(sel ^ 1) * (TM + TN) * KP);
       __syncthreads();
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(
     const __amdgpu_buffer_rsrc_t rz = make_rsrc(has_z ? Z + r0 * ldz + n0 : Y, has_z ? win_bytes(nr, ldz, ncols) : 0);
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(has_add ? add + r0 * ldadd + n0 : Y, has_add ? win_bytes(nr, ldadd, ncols) : 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int col = wn * 64 + j * 32 + (lane_e & 31);
@@ -178,13 +184,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(
         float zv[16], av[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int rr = wm * 64 + i * 32 + d_row(r, lane_e);
+          const int rr = wm * 32 * MI + i * 32 + d_row(r, lane_e);
           zv[r] = buf_ld1(rz, jok ? (unsigned)((rr * ldz + col) * 4) : kOOB);    // 0 when absent
           av[r] = buf_ld1(ra, jok ? (unsigned)((rr * ldadd + col) * 4) : kOOB);  // 0 when absent
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int rr = wm * 64 + i * 32 + d_row(r, lane_e);
+          const int rr = wm * 32 * MI + i * 32 + d_row(r, lane_e);
           float v = acc[i][j][r];
           if (EPI == EPI_DX) {
             if (silu) {  // block-uniform
@@ -218,6 +224,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(
 }
 
 struct GtGeom {
+  int mi;
   int nt;
   int64_t total;
   int per_xcd;
@@ -226,12 +233,18 @@ struct GtGeom {
 static inline GtGeom gt_geom(int64_t rows, int N) {
   GtGeom g;
   g.nt = (N + kGtTN - 1) / kGtTN;
-  g.total = gcl::cdiv(rows, kGtTM) * g.nt;
+  // 128-row tiles unless they would give the 512 persistent blocks fewer than ~3 tiles each
+  g.mi = (gcl::cdiv(rows, 128) * g.nt < 3 * 2 * gcl::kNumCU) ? 1 : 2;  // env GCL_GT_MI overrides (experiments)
+  static const int force = [] { const char* e = getenv("GCL_GT_MI"); return e ? atoi(e) : 0; }();
+  if (force == 1 || force == 2) g.mi = force;
+  const int TM = 64 * g.mi;
+  g.total = gcl::cdiv(rows, TM) * g.nt;
   // whole row tiles per XCD so that the column tiles of a row tile share an L2
-  const int64_t row_tiles_per_xcd = gcl::cdiv(gcl::cdiv(rows, kGtTM), gcl::kNumXCD);
+  const int64_t row_tiles_per_xcd = gcl::cdiv(gcl::cdiv(rows, TM), gcl::kNumXCD);
   g.per_xcd = (int)(row_tiles_per_xcd * g.nt);
-  // persistent: two resident blocks per CU (LDS-limited), i.e. 64 slots per XCD
-  const int slots = g.per_xcd < 2 * gcl::kNumCU / gcl::kNumXCD ? g.per_xcd : 2 * gcl::kNumCU / gcl::kNumXCD;
+  // persistent: the resident blocks per CU (LDS-limited: 2 at 128-row tiles, 3 at 64-row tiles)
+  const int cap = (g.mi == 1 ? 3 : 2) * gcl::kNumCU / gcl::kNumXCD;
+  const int slots = g.per_xcd < cap ? g.per_xcd : cap;
   g.grid = (unsigned)(slots * gcl::kNumXCD);
   return g;
 }

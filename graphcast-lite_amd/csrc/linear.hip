@@ -939,6 +939,85 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const float* __restri
   }
 }
 
+// Same contract, 16-byte loads: a block reduces 32 consecutive floats of the record (8 lanes x float4 =
+// one 128-B line per partial record) with 32 groups of lanes striding over the records, then a
+// fixed-order combine through LDS.  Needs pstride, every poff and every count to be multiples of 4.
+__global__ __launch_bounds__(256) void reduce_multi4_kernel(const float* __restrict__ part, int32_t nparts,
+                                                            int64_t pstride, RedSeg s0, RedSeg s1, RedSeg s2,
+                                                            int32_t accumulate) {
+  __shared__ float red[32][33];
+  const int l8 = threadIdx.x & 7, g = threadIdx.x >> 3;
+  int idx = blockIdx.x * 32 + l8 * 4;  // first of this lane's 4 elements, in the concatenated segments
+  RedSeg sg = s0;
+  if (idx >= s0.count) {
+    idx -= s0.count;
+    sg = s1;
+    if (idx >= s1.count) {
+      idx -= s1.count;
+      sg = s2;
+    }
+  }
+  const bool ok = idx < sg.count;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) {
+    const float* base = part + sg.poff + idx;
+    int p = g;
+    for (; p + 96 < nparts; p += 128) {  // four records in flight per lane
+      const float4 a = *reinterpret_cast<const float4*>(base + (size_t)p * pstride);
+      const float4 b = *reinterpret_cast<const float4*>(base + (size_t)(p + 32) * pstride);
+      const float4 c = *reinterpret_cast<const float4*>(base + (size_t)(p + 64) * pstride);
+      const float4 d = *reinterpret_cast<const float4*>(base + (size_t)(p + 96) * pstride);
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+      s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+      s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+    }
+    for (; p < nparts; p += 32) {
+      const float4 a = *reinterpret_cast<const float4*>(base + (size_t)p * pstride);
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+  }
+  red[g][l8 * 4] = s.x; red[g][l8 * 4 + 1] = s.y; red[g][l8 * 4 + 2] = s.z; red[g][l8 * 4 + 3] = s.w;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    // element threadIdx.x of the block: recompute its segment position (its lane group's idx + offset)
+    int e = blockIdx.x * 32 + threadIdx.x;
+    RedSeg so = s0;
+    if (e >= s0.count) {
+      e -= s0.count;
+      so = s1;
+      if (e >= s1.count) {
+        e -= s1.count;
+        so = s2;
+      }
+    }
+    if (e < so.count) {
+      float tot = 0.f;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) tot += red[q][threadIdx.x];
+      const int i = e / so.pld, j = e - i * so.pld;
+      if (j < so.cols) {
+        float* o = so.out + (size_t)i * so.ldo + j;
+        *o = accumulate ? *o + tot : tot;
+      }
+    }
+  }
+}
+
+// picks the 16-byte variant when the record layout allows it
+inline void launch_reduce_multi(const float* part, int nparts, int64_t pstride, const RedSeg& s0, const RedSeg& s1,
+                                const RedSeg& s2, int accumulate, hipStream_t st) {
+  const int total = s0.count + s1.count + s2.count;
+  const bool vec = (pstride % 4 == 0) && ((s0.poff | s1.poff | s2.poff | s0.count | s1.count | s2.count) % 4 == 0) &&
+                   gcl::aligned16(part) && nparts >= 64;
+  if (vec)
+    hipLaunchKernelGGL(reduce_multi4_kernel, dim3((unsigned)gcl::cdiv(total, 32)), dim3(256), 0, st, part, nparts, pstride,
+                       s0, s1, s2, accumulate);
+  else
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)gcl::cdiv(total, 16)), dim3(256), 0, st, part, nparts, pstride,
+                       s0, s1, s2, accumulate);
+}
+
 }  // namespace
 
 namespace gcl {
@@ -947,8 +1026,7 @@ int launch_reduce_parts(const float* part, int nparts, int64_t pstride, int pld,
   // one segment of the 16-way reducer: R rows of pld (padded) columns, C of them valid
   RedSeg s0{out, 0, R * pld, pld, C, ldo};
   RedSeg none{nullptr, 0, 0, 1, 0, 0};
-  hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)cdiv((int64_t)R * pld, 16)), dim3(256), 0, st, part, nparts,
-                     pstride, s0, none, none, accumulate);
+  launch_reduce_multi(part, nparts, pstride, s0, none, none, accumulate, st);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
@@ -1084,16 +1162,21 @@ int launch_gemm(const float* X, int64_t ldx, int akind, const float* slope, cons
   GCL_CHECK_ARG((K % 4 == 0) && (ldx % 4 == 0) && gcl::aligned16(X), "dense: wide shapes need K %% 4 == 0 and 16-B aligned rows (K=%d ldx=%lld)", K, (long long)ldx);
   GCL_CHECK_ARG((ldw % 4 == 0) && gcl::aligned16(W) && (!trans || N % 4 == 0), "dense: wide shapes need a 16-B aligned weight block (ldw=%lld N=%d)", (long long)ldw, N);
   const GtGeom g = gt_geom(rows, N);
-#define GCL_GT(T_)                                                                                                \
+#define GCL_GT(T_, MI_)                                                                                           \
   do {                                                                                                            \
-    auto kern = gemm_tile_kernel<EPI, T_>;                                                                        \
+    auto kern = gemm_tile_kernel<EPI, T_, MI_>;                                                                   \
     { static bool lds_set = false;                                                                                \
       if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
-    hipLaunchKernelGGL(kern, dim3(g.grid), dim3(256), kGtLds, st, X, ldx, akind, slope, W, ldw, bias, Y, ldy, rows, \
-                       K, N, Z, ldz, add, ldadd, slope_part, g.nt, g.total, g.per_xcd);                           \
+    hipLaunchKernelGGL(kern, dim3(g.grid), dim3(256), gt_lds(MI_), st, X, ldx, akind, slope, W, ldw, bias, Y, ldy, \
+                       rows, K, N, Z, ldz, add, ldadd, slope_part, g.nt, g.total, g.per_xcd);                     \
   } while (0)
-  if (trans) GCL_GT(true);
-  else GCL_GT(false);
+  if (trans) {
+    if (g.mi == 1) GCL_GT(true, 1);
+    else GCL_GT(true, 2);
+  } else {
+    if (g.mi == 1) GCL_GT(false, 1);
+    else GCL_GT(false, 2);
+  }
 #undef GCL_GT
   GCL_CHECK_LAUNCH();
   if (nparts) *nparts = (int)g.grid;
@@ -1370,9 +1453,7 @@ extern "C" int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W,
     RedSeg s0{dW, 0, Fout * FiP, FiP, Fin, Fin};
     RedSeg s1{db, FoP * FiP, db ? Fout : 0, FoP, Fout, 0};
     RedSeg s2{colsum_dx, FoP * FiP + FoP, colsum_dx ? Fin : 0, FiP, Fin, 0};
-    const int total = s0.count + s1.count + s2.count;
-    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)gcl::cdiv(total, 16)), dim3(256), 0, st, part_dw, nblk, rec,
-                       s0, s1, s2, accumulate);
+    launch_reduce_multi(part_dw, nblk, rec, s0, s1, s2, accumulate, st);
     GCL_CHECK_LAUNCH();
   }
   if (want_slope) {

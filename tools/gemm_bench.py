@@ -24,7 +24,7 @@ def t(fn, n=10):
 
 
 import os
-shapes = [(327680, 256, 256), (327680, 512, 256), (40962, 256, 512), (327680, 128, 128), (327680, 256, 128)]
+shapes = [(327680, 256, 256), (327680, 512, 256), (40962, 256, 512), (40962, 256, 256), (81924, 256, 256), (327680, 128, 128), (327680, 256, 128)]
 if os.environ.get('GCL_DENSE_IMPL'):
     shapes = [(327680, 128, 128), (786432, 64, 128), (786432, 128, 64), (786432, 64, 64), (327680, 128, 256), (327680, 256, 64)]
 for rows, K, N in shapes:
