@@ -448,3 +448,49 @@ def test_activation_variants(family, act):
         # side of 0 in one of the two fp32 implementations flips a whole element (PReLU: 1 - slope of it)
         tol = 3e-3 if act == "relu" else 1e-4
         assert d <= tol * float(og[n_].grad.double().norm()) + 1e-6 * gn, (n_, d)
+
+
+def test_interaction_net_without_layer_norm_and_graph_capture():
+    """InteractionNet with use_layer_norm=False (src/models.py:381) matches the oracle, and a TrainStep on an
+    InteractionNet model replays from a captured hipGraph like eager launches."""
+    from graphcast_lite_amd.train import TrainStep, batch_loss, get_lat_weights
+
+    import conftest
+    base = conftest.experiment
+
+    def patched(nm, mesh_levels=None):
+        cfg = base(nm, mesh_levels=mesh_levels)
+        cfg.pipeline.processor.gcn.use_layer_norm = False
+        cfg.pipeline.processor.gcn.num_message_passing_steps = 3
+        return cfg
+
+    global experiment
+    saved, experiment = experiment, patched
+    try:
+        cfg, m, o = make_pair("region_krsk_cds_19f", [1, 2])
+    finally:
+        experiment = saved
+    assert not hasattr(m.processor.graph_layer.layers.steps[0], "edge_norm")
+    X, y = data(cfg, m._num_grid_nodes, 2)
+    assert rel(m(X.to(DEV)), o(X)) < 1e-5
+    lw = T.get_lat_weights(32, 64)
+    T.train_step_loss(o, X, y, lat_weights=lw).backward()
+    batch_loss(m, X.to(DEV), y.to(DEV), lat_weights=get_lat_weights(32, 64, DEV)).backward()
+    og = dict(o.named_parameters())
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in og.values() if p.grad is not None)))
+    for n_, p in m.named_parameters():
+        if og[n_].grad is None:
+            continue
+        d = float((p.grad.double().cpu() - og[n_].grad.double()).norm())
+        assert d <= 1e-4 * float(og[n_].grad.double().norm()) + 1e-6 * gn, (n_, d)
+
+    _, m1, _ = make_pair("region_krsk_cds_19f", [1, 2])
+    _, m2, _ = make_pair("region_krsk_cds_19f", [1, 2])
+    lwd = get_lat_weights(32, 64, DEV)
+    s1, s2 = TrainStep(m1, lr=1e-3, lat_weights=lwd, use_graph=True), TrainStep(m2, lr=1e-3, lat_weights=lwd, use_graph=False)
+    Xd, yd = X.to(DEV), y.to(DEV)
+    for i in range(5):
+        l1, l2 = s1(Xd * (1 + 0.01 * i), yd), s2(Xd * (1 + 0.01 * i), yd)
+        assert rel(l1, l2) < 1e-6, (i, float(l1), float(l2))
+    if s1.use_graph:
+        assert s1._graph is not None
