@@ -88,8 +88,17 @@ def cpu_baseline(cfg, model, grid, budget_s=12.0, max_steps=2000):
         one()
         n += 1
     dt = time.perf_counter() - t0
+    # the same step on ONE thread (SURVEY.md §8d asks for both), a few seconds of it
+    torch.set_num_threads(1)
+    n1, t1 = 0, time.perf_counter()
+    while n1 == 0 or (n1 < max_steps and (time.perf_counter() - t1) < min(4.0, budget_s / 3)):
+        one()
+        n1 += 1
+    dt1 = time.perf_counter() - t1
+    torch.set_num_threads(cores)
     return {"value": n / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{n} optimiser steps at batch 1 (fwd+loss+bwd+Adam) of the same config, {dt:.1f} s"}
+            "sample": f"{n} optimiser steps at batch 1 (fwd+loss+bwd+Adam) of the same config, {dt:.1f} s",
+            "value_1thread": n1 / dt1}
 
 
 def main():
@@ -102,9 +111,10 @@ def main():
                     choices=["baseline", "attention", "attention_h4", "sparse_attention", "wb2_512x256_19f_ar",
                              "wb2_512x256_19f_ar_v2", "region_krsk_cds_19f"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the step from a captured hipGraph (1 GPU). Off by default: launches inside a "
-                         "replayed graph cannot be bracketed by HIP events, which the roofline line needs")
+    ap.add_argument("--eager", action="store_true",
+                    help="launch every kernel of the timed steps individually instead of replaying the captured "
+                         "hipGraph (then the roofline events are recorded inside the timed region itself)")
+    ap.add_argument("--graph", action="store_true", help="(default) kept for older command lines")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,7 +137,7 @@ def main():
     X, y = synthetic_batch(cfg, G, B, seed=1234 + rank)  # every rank its own samples
     X, y = X.to(dev), y.to(dev)                           # resident in HBM before the timed region
     step = TrainStep(model, lr=1e-3, lat_weights=get_lat_weights(grid[0], grid[1], dev), world_size=world,
-                     use_graph=bool(args.graph) and world == 1)
+                     use_graph=not args.eager)
 
     # Untimed settle phase before the W official warm-up steps: a freshly acquired box can run the
     # first seconds several times slower (clock ramp / code-object and allocator warm-up).  Step until
@@ -146,15 +156,21 @@ def main():
             break
     for _ in range(args.warmup):
         loss = step(X, y)
-    # time the mesh-processor aggregation launches (forward) inside the timed region
     is_gcn = cfg.pipeline.processor.gcn.layer_type.value == "conv_gcn"
     is_inet = cfg.pipeline.processor.gcn.layer_type.value == "interaction_net"
-    if is_gcn:
-        pg = models._graphs.get(model.processing_graph, M, hip.GRAPH_GCN)
-        hip.AGG_PROFILE = {"graph": pg, "events": []}
-    if is_inet:  # the edge-MLP contractions [B*E, D] x [D, D]: 2 per message-passing step, forward
-        D, E = cfg.pipeline.processor.gcn.output_dim, int(model.processing_graph.shape[1])
-        hip.DENSE_PROFILE = {"rows": B * E, "Fin": D, "Fout": D, "events": []}
+
+    def arm_profile():
+        # HIP events around the roofline kernel's launches (recorded on the launch stream)
+        if is_gcn:
+            hip.AGG_PROFILE = {"graph": models._graphs.get(model.processing_graph, M, hip.GRAPH_GCN), "events": []}
+        if is_inet:  # the edge-MLP contractions [B*E, D] x [D, D]: 2 per message-passing step, forward
+            hip.DENSE_PROFILE = {"rows": B * int(model.processing_graph.shape[1]),
+                                 "Fin": cfg.pipeline.processor.gcn.output_dim,
+                                 "Fout": cfg.pipeline.processor.gcn.output_dim, "events": []}
+
+    replayed = bool(step.use_graph and step._graph is not None)
+    if not replayed:
+        arm_profile()  # eager timed region: the events sit inside it
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -165,6 +181,19 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    roof_steps, roof_ms = args.steps, None
+    if replayed:
+        # Kernels replayed from a hipGraph cannot be bracketed by timing events on ROCm, so the
+        # roofline kernel is timed on a few eager steps of the SAME step function right after the
+        # timed region (same buffers, same launches; the rocprofv3 trace in profiles/ covers both).
+        arm_profile()
+        roof_steps = max(3, min(args.steps, 10))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(roof_steps):
+            loss = step._eager(X, y)
+        torch.cuda.synchronize()
+        roof_ms = (time.perf_counter() - t1) / roof_steps * 1e3
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -182,20 +211,41 @@ def main():
     except Exception:
         pass
     roof = None
+
+    def copy_ceiling_gbs():
+        """Stream-copy ceiling of THIS box: 256 MiB device-to-device copy, read + write bytes."""
+        a = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+        b = torch.empty_like(a)
+        for _ in range(3):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        return 2.0 * a.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
     if is_gcn and hip.AGG_PROFILE["events"]:
         ev = hip.AGG_PROFILE["events"]
         ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
         F = cfg.pipeline.processor.gcn.output_dim
+        pg = hip.AGG_PROFILE["graph"]
         Ep = pg.e
         per_sample = 4 * M * (F + F) + 4 * Ep + 4 * (M + 1) + 4 * M  # SURVEY.md §8d
         achieved = B * per_sample / (ms * 1e-3) / 1e9
+        copy_gbs = copy_ceiling_gbs()
+        gather_counted = B * (per_sample + 4 * Ep * F) / (ms * 1e-3) / 1e9  # what an edge-wise gather would move
         roof = {"bound": "hbm", "kernel": "agg_kernel (mesh GCNConv aggregate, forward)", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "bytes_per_launch": B * per_sample, "avg_launch_us": ms * 1e3, "launches_timed": len(ev)}
+                "bytes_per_launch": B * per_sample, "avg_launch_us": ms * 1e3, "launches_timed": len(ev),
+                "copy_ceiling_gbs": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,
+                "achieved_gather_counted_gbs": gather_counted}
     hip.AGG_PROFILE = None
     if is_inet and hip.DENSE_PROFILE["events"]:
         ev = hip.DENSE_PROFILE["events"]
         ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        D, E = cfg.pipeline.processor.gcn.output_dim, int(model.processing_graph.shape[1])
         flops = 2.0 * B * E * D * D
         achieved = flops / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "gemm_tile_kernel (InteractionNet edge MLP, [B*E, D] x [D, D], forward)",
@@ -214,10 +264,14 @@ def main():
                                    f"G={G}, mesh M={M}, {cfg.data.num_features_used} feat, obs 2, AR 1, "
                                    f"fwd+loss+bwd+Adam", "batch_per_gpu": B, "global_batch": B * args.gpus,
                        "parallelism": f"dp{args.gpus}", "final_loss": final_loss,
-                       "launch_mode": "hipGraph replay" if step.use_graph else "eager",
+                       "launch_mode": ("hipGraph replay" + (" (fwd+bwd; all-reduce + Adam eager)" if step.split_finish else "")
+                                       if replayed else "eager"),
                        "settle_steps_before_warmup": settle},
             "roofline": roof,
         }
+        if roof is not None:
+            roof["measured_on"] = (f"{roof_steps} eager steps right after the timed region ({roof_ms:.2f} ms/step eager)"
+                                   if replayed else "the timed steps themselves")
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model, grid)
         print(json.dumps(out), flush=True)

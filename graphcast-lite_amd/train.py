@@ -307,45 +307,65 @@ class FusedAdam:
 class TrainStep:
     """One optimiser step on a local batch: forward, loss, backward, [all-reduce], Adam.
 
-    With `use_graph` (default, single GPU only) the whole step - ~160 kernel launches - is captured
+    With `use_graph` (default) the launch-heavy part of the step - ~160 kernel launches - is captured
     once into a hipGraph (via torch.cuda.CUDAGraph on the stream the kernels are enqueued on) and
-    replayed; inputs are copied into static buffers first.  Multi-GPU keeps eager launches so the
-    RCCL all-reduce stays an ordinary stream operation between backward and Adam."""
+    replayed; inputs are copied into static buffers first.  One GPU: the whole step including Adam
+    is in the graph.  Several GPUs (or `split_finish`): zero-grad + forward + loss + backward are in
+    the graph and the RCCL all-reduce + Adam stay ordinary stream operations after the replay, so
+    no collective is ever captured.  A step then costs the host one graph launch instead of ~160
+    kernel launches, which keeps it GPU-bound on hosts with slow launch paths."""
 
     def __init__(self, model, lr=1e-3, lat_weights=None, channel_mask=None, spatial_mask=None, use_residual=True,
-                 ar_steps=1, world_size=1, use_graph=None):
+                 ar_steps=1, world_size=1, use_graph=None, split_finish=None):
         self.model = model
         self.flat = FlatParams(model)
         self.opt = FusedAdam(self.flat, lr=lr)
         self.lat_weights, self.channel_mask, self.spatial_mask = lat_weights, channel_mask, spatial_mask
         self.use_residual, self.ar_steps, self.world = use_residual, ar_steps, world_size
         if use_graph is None:
-            use_graph = world_size == 1 and os.environ.get("GCL_NO_GRAPH", "0") in ("0", "")
+            use_graph = os.environ.get("GCL_NO_GRAPH", "0") in ("0", "")
         self.use_graph = bool(use_graph) and not getattr(model, "using_sparse_gat", False)
+        self.split_finish = (world_size > 1) if split_finish is None else bool(split_finish or world_size > 1)
         self._graph, self._sX, self._sy, self._sloss, self._eager_calls = None, None, None, None, 0
 
-    def _eager(self, X, y, threshold=0.0, epoch=0, batch_num=1):
+    def _fwd_bwd(self, X, y, threshold=0.0, epoch=0, batch_num=1):
         self.flat.zero_grad()
         loss = batch_loss(self.model, X, y, threshold, epoch, batch_num, self.lat_weights, self.ar_steps,
                           self.channel_mask, self.spatial_mask, None, None, self.use_residual)
         loss.backward()
+        return loss.detach()
+
+    def _finish(self):
         scale = allreduce_gradients(self.flat, self.world)
         self.opt.step(grad_scale=scale)
-        return loss.detach()
+
+    def _eager(self, X, y, threshold=0.0, epoch=0, batch_num=1):
+        loss = self._fwd_bwd(X, y, threshold, epoch, batch_num)
+        self._finish()
+        return loss
 
     def _capture(self, X, y):
         self._sX, self._sy = X.clone(), y.clone()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._sloss = self._eager(self._sX, self._sy)
+        # thread_local: other threads of the process (the RCCL watchdog) may touch the runtime meanwhile
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            self._sloss = self._fwd_bwd(self._sX, self._sy)
+            if not self.split_finish:
+                self._finish()
         self._graph = g
+
+    def _replay(self):
+        self._graph.replay()
+        if self.split_finish:
+            self._finish()
+        return self._sloss.detach()
 
     def __call__(self, X, y, threshold=0.0, epoch=0, batch_num=1):
         if not self.use_graph:
             return self._eager(X, y, threshold, epoch, batch_num)
         if self._graph is None:
-            # a few eager steps first: workspaces, CSR handles and kernel attributes get set up
-            # outside the capture
+            # a few eager steps first: workspaces, CSR handles, kernel attributes and the RCCL
+            # communicator get set up outside the capture
             if self._eager_calls < 2:
                 self._eager_calls += 1
                 return self._eager(X, y, threshold, epoch, batch_num)
@@ -357,11 +377,9 @@ class TrainStep:
                 self.use_graph, self._graph = False, None
                 torch.cuda.synchronize()
                 return self._eager(X, y, threshold, epoch, batch_num)
-            self._graph.replay()  # capture only records; the first replay performs this step
-            return self._sloss.detach()
+            return self._replay()  # capture only records; the first replay performs this step
         if X.shape != self._sX.shape:
             return self._eager(X, y, threshold, epoch, batch_num)
         self._sX.copy_(X)
         self._sy.copy_(y)
-        self._graph.replay()
-        return self._sloss.detach()
+        return self._replay()

@@ -208,20 +208,24 @@ def test_graph_captured_step_equals_eager():
 
     cfg, m1, _ = make_pair("baseline", [1, 2])
     _, m2, _ = make_pair("baseline", [1, 2])
+    _, m3, _ = make_pair("baseline", [1, 2])
     X, y = data(cfg, m1._num_grid_nodes, 4)
     Xd, yd = X.to(DEV), y.to(DEV)
     lw = get_lat_weights(32, 64, DEV)
     s1 = TrainStep(m1, lr=1e-3, lat_weights=lw, use_graph=True)
     s2 = TrainStep(m2, lr=1e-3, lat_weights=lw, use_graph=False)
+    # the multi-GPU arrangement: forward + backward replayed, all-reduce + Adam launched after the replay
+    s3 = TrainStep(m3, lr=1e-3, lat_weights=lw, use_graph=True, split_finish=True)
     for i in range(6):
-        l1, l2 = s1(Xd * (1 + 0.01 * i), yd), s2(Xd * (1 + 0.01 * i), yd)
-        assert rel(l1, l2) < 1e-6, (i, float(l1), float(l2))
-    assert s1.opt.t == s2.opt.t == 6
-    if s1.use_graph:
-        assert s1._graph is not None
-    p2 = dict(m2.named_parameters())
+        l1, l2, l3 = s1(Xd * (1 + 0.01 * i), yd), s2(Xd * (1 + 0.01 * i), yd), s3(Xd * (1 + 0.01 * i), yd)
+        assert rel(l1, l2) < 1e-6 and rel(l3, l2) < 1e-6, (i, float(l1), float(l2), float(l3))
+    assert s1.opt.t == s2.opt.t == s3.opt.t == 6
+    for s_ in (s1, s3):
+        if s_.use_graph:
+            assert s_._graph is not None
+    p2, p3 = dict(m2.named_parameters()), dict(m3.named_parameters())
     for n_, p in m1.named_parameters():
-        assert rel(p, p2[n_]) < 1e-6, n_
+        assert rel(p, p2[n_]) < 1e-6 and rel(p3[n_], p2[n_]) < 1e-6, n_
 
 
 def test_reference_style_training_loop():
