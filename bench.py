@@ -122,8 +122,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # rehearsal knobs for a one-GPU box (never used by the driver): GCL_DIST_BACKEND=gloo lets several
+        # ranks share device 0 (RCCL refuses two ranks on one device), GCL_BENCH_ONE_DEVICE=1 maps them there
+        dist.init_process_group(os.environ.get("GCL_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("GCL_BENCH_ONE_DEVICE", "0") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
