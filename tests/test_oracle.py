@@ -298,3 +298,23 @@ def test_window_sample_hand_case_and_split_indices():
     assert sample_indices([2], 2, 1, "all", 0.2) == []
     with pytest.raises(ValueError):
         sample_indices([10], 2, 1, "nope", 0.2)
+
+
+def test_interaction_net_v2_parameter_count():
+    """experiments/wb2_512x256_19f_ar_v2: the module tree built from the config has the sizes that
+    src/models.py:166-285 implies - per step (768*256+256) + (256*256+256) edge MLP, (512*256+256) +
+    (256*256+256) node MLP, 4*256 norms; edge encoder 4*256+256 - i.e. 5 530 880 in the processor and
+    6 022 551 in all, the "~5.9M" (28x the ~210K of v1) that README_RU.MD:142,242 quotes."""
+    from graphcast_lite_amd.models import Model
+    from oracle import model as OM
+
+    cfg = experiment("wb2_512x256_19f_ar_v2")
+    count = lambda m: sum(p.numel() for p in m.parameters())
+    per_step = (768 * 256 + 256) + (256 * 256 + 256) + (512 * 256 + 256) + (256 * 256 + 256) + 4 * 256
+    for mk in (Model, OM.Model):
+        enc = mk(cfg.pipeline.encoder, 2 * 19 + 6)
+        proc = mk(cfg.pipeline.processor, enc.output_dim)
+        dec = mk(cfg.pipeline.decoder, proc.output_dim)
+        assert count(proc) == 12 * per_step + 4 * 256 + 256 == 5_530_880
+        total = count(enc) + count(proc) + count(dec)
+        assert total == 6_022_551 and abs(total / 209_882 - 28) < 1.0
