@@ -220,9 +220,8 @@ def test_graph_captured_step_equals_eager():
         l1, l2, l3 = s1(Xd * (1 + 0.01 * i), yd), s2(Xd * (1 + 0.01 * i), yd), s3(Xd * (1 + 0.01 * i), yd)
         assert rel(l1, l2) < 1e-6 and rel(l3, l2) < 1e-6, (i, float(l1), float(l2), float(l3))
     assert s1.opt.t == s2.opt.t == s3.opt.t == 6
-    for s_ in (s1, s3):
-        if s_.use_graph:
-            assert s_._graph is not None
+    for s_ in (s1, s3):  # the capture itself must have succeeded on this box (no silent eager fallback)
+        assert s_.use_graph and s_._graph is not None
     p2, p3 = dict(m2.named_parameters()), dict(m3.named_parameters())
     for n_, p in m1.named_parameters():
         assert rel(p, p2[n_]) < 1e-6 and rel(p3[n_], p2[n_]) < 1e-6, n_
@@ -496,5 +495,25 @@ def test_interaction_net_without_layer_norm_and_graph_capture():
     for i in range(5):
         l1, l2 = s1(Xd * (1 + 0.01 * i), yd), s2(Xd * (1 + 0.01 * i), yd)
         assert rel(l1, l2) < 1e-6, (i, float(l1), float(l2))
-    if s1.use_graph:
-        assert s1._graph is not None
+    assert s1.use_graph and s1._graph is not None
+
+
+def test_captured_rollout_equals_eager_rollout():
+    """predict.CapturedRollout (the K-step forecast replayed from one hipGraph) == predict.rollout."""
+    from graphcast_lite_amd.predict import CapturedRollout, rollout
+
+    cfg, m, _ = make_pair("baseline", [1, 2])
+    G, F = m._num_grid_nodes, cfg.data.num_features_used
+    m.eval()
+    cap = CapturedRollout(m, 3, static_channels=[F - 1], forcing_channels=[0])
+    g = torch.Generator().manual_seed(3)
+    for i in range(5):  # two eager calls, the capturing call, two replays
+        X = torch.randn(1, G, 2 * F, generator=g).to(DEV)
+        y = torch.randn(1, G, 3 * F, generator=g).to(DEV)
+        want = rollout(m, X, 3, y=y, static_channels=[F - 1], forcing_channels=[0])
+        got = cap(X, y)
+        assert torch.equal(got, want), i
+    assert cap.enabled and cap._graph is not None  # the capture itself must have succeeded on this box
+    # a new input signature starts over (eager, then a fresh capture)
+    X2 = torch.randn(2, G, 2 * F, generator=g).to(DEV)
+    assert torch.equal(cap(X2), rollout(m, X2, 3, static_channels=[F - 1], forcing_channels=[0]))
