@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="samples per GPU (default: 64 at 64x32, 8 at 512x256)")
     ap.add_argument("--config", default="baseline",
                     choices=["baseline", "attention", "attention_h4", "sparse_attention", "wb2_512x256_19f_ar",
-                             "wb2_512x256_19f_ar_v2", "region_krsk_cds_19f"])
+                             "wb2_512x256_19f_ar_v2", "region_krsk_cds_19f", "wb2_512x256_sparse_gat"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true",
                     help="launch every kernel of the timed steps individually instead of replaying the captured "
@@ -136,7 +136,7 @@ def main():
 
     hip.lib()
     cfg, model, grid = build_model(args.config, dev)
-    B = args.batch or {"wb2_512x256_19f_ar": 8, "wb2_512x256_19f_ar_v2": 1}.get(args.config, 64)
+    B = args.batch or {"wb2_512x256_19f_ar": 8, "wb2_512x256_sparse_gat": 8, "wb2_512x256_19f_ar_v2": 1}.get(args.config, 64)
     G, M = model._num_grid_nodes, model._num_mesh_nodes
     X, y = synthetic_batch(cfg, G, B, seed=1234 + rank)  # every rank its own samples
     X, y = X.to(dev), y.to(dev)                           # resident in HBM before the timed region

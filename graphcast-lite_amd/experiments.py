@@ -34,7 +34,7 @@ def _interaction_pipeline(F, steps, enc_hidden, dec_mlp_hidden, dec_mlp_out, dec
     }
 
 
-GRID = {"wb2_512x256_19f_ar_v2": (256, 512), "region_krsk_cds_19f": (32, 64), "baseline": (32, 64), "attention": (32, 64), "attention_h4": (32, 64), "sparse_attention": (32, 64),
+GRID = {"wb2_512x256_sparse_gat": (256, 512), "wb2_512x256_19f_ar_v2": (256, 512), "region_krsk_cds_19f": (32, 64), "baseline": (32, 64), "attention": (32, 64), "attention_h4": (32, 64), "sparse_attention": (32, 64),
         "wb2_512x256_19f_ar": (256, 512)}
 
 
@@ -54,6 +54,12 @@ def experiment(name: str, mesh_levels=None) -> ExperimentConfig:
         data.update(num_features_used=12)
     elif name == "wb2_512x256_19f_ar":
         pipe = _pipeline([128, 128], 128, "conv_gcn", [128] * 4, [128, 64], 64, [64, 64], 19)
+        graph.update(grid2mesh_radius_query=0.6, mesh_levels=mesh_levels or [4, 6])
+        data.update(num_features_used=19)
+    elif name == "wb2_512x256_sparse_gat":
+        # BASELINE.json configs[4]: the 512x256 encoder / decoder with ONE SparseGATConv(128 -> 128, H = 1) + LN as
+        # processor.  The reference has no config file for this combination.
+        pipe = _pipeline([128, 128], 128, "sparse_gat", [], [128, 64], 64, [64, 64], 19)
         graph.update(grid2mesh_radius_query=0.6, mesh_levels=mesh_levels or [4, 6])
         data.update(num_features_used=19)
     elif name == "wb2_512x256_19f_ar_v2":  # latent 256, 12 unshared InteractionNet steps, swish
