@@ -324,7 +324,8 @@ class TrainStep:
         self.use_residual, self.ar_steps, self.world = use_residual, ar_steps, world_size
         if use_graph is None:
             use_graph = os.environ.get("GCL_NO_GRAPH", "0") in ("0", "")
-        self.use_graph = bool(use_graph) and not getattr(model, "using_sparse_gat", False)
+        self.use_graph = bool(use_graph)
+        self._sparse = bool(getattr(model, "using_sparse_gat", False))
         self.split_finish = (world_size > 1) if split_finish is None else bool(split_finish or world_size > 1)
         self._graph, self._sX, self._sy, self._sloss, self._eager_calls = None, None, None, None, 0
 
@@ -362,6 +363,12 @@ class TrainStep:
 
     def __call__(self, X, y, threshold=0.0, epoch=0, batch_num=1):
         if not self.use_graph:
+            return self._eager(X, y, threshold, epoch, batch_num)
+        if self._sparse and batch_num == 0:
+            # SparseGATConv prunes the mesh graph on this step (src/models.py:138-149): run it eagerly and
+            # drop the captured graph, which was recorded over the old edge list; two eager steps follow so
+            # that the CSR of the pruned list (and of its loop-completed form) exists before re-capturing
+            self._graph, self._eager_calls = None, 0
             return self._eager(X, y, threshold, epoch, batch_num)
         if self._graph is None:
             # a few eager steps first: workspaces, CSR handles, kernel attributes and the RCCL

@@ -517,3 +517,31 @@ def test_captured_rollout_equals_eager_rollout():
     # a new input signature starts over (eager, then a fresh capture)
     X2 = torch.randn(2, G, 2 * F, generator=g).to(DEV)
     assert torch.equal(cap(X2), rollout(m, X2, 3, static_channels=[F - 1], forcing_channels=[0]))
+
+
+def test_sparse_gat_train_step_graph_replay_follows_pruning():
+    """TrainStep on a SparseGAT model: ordinary steps replay a captured hipGraph, the pruning step
+    (batch_num == 0) runs eagerly and forces a re-capture over the pruned edge list; the trajectory
+    equals all-eager launches."""
+    from graphcast_lite_amd.train import TrainStep, get_lat_weights
+
+    cfg, m1, _ = make_pair("sparse_attention", [1, 2])
+    _, m2, _ = make_pair("sparse_attention", [1, 2])
+    X, y = data(cfg, m1._num_grid_nodes, 3)
+    Xd, yd = X.to(DEV), y.to(DEV)
+    lw = get_lat_weights(32, 64, DEV)
+    s1 = TrainStep(m1, lr=1e-3, lat_weights=lw, use_graph=True)
+    s2 = TrainStep(m2, lr=1e-3, lat_weights=lw, use_graph=False)
+    e0 = int(m1.processing_graph.shape[1])
+    schedule = [1, 2, 3, 4, 0, 1, 2, 3, 4]  # the 5th step prunes (as batch 0 of an epoch does, src/train.py:197)
+    for i, bn in enumerate(schedule):
+        l1 = s1(Xd, yd, threshold=0.12, epoch=0, batch_num=bn)
+        l2 = s2(Xd, yd, threshold=0.12, epoch=0, batch_num=bn)
+        assert rel(l1, l2) < 1e-6, (i, float(l1), float(l2))
+        if i == 3:
+            assert s1._graph is not None  # replaying before the prune
+    assert torch.equal(m1.processing_graph, m2.processing_graph)
+    assert int(m1.processing_graph.shape[1]) < e0 + m1._num_mesh_nodes  # pruned
+    assert s1.use_graph and s1._graph is not None  # re-captured after the prune
+    for (n_, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert rel(p, q) < 1e-6, n_
