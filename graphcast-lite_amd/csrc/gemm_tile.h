@@ -141,23 +141,35 @@ __global__ __launch_bounds__(256, (MI == 1 ? 3 : 2)) void gemm_tile_kernel(
       else if (more) issue(nr0, nn0, 0);
       const float* ap = buf + (wm * 32 * MI + (lane & 31)) * KP + 2 * (lane >> 5);
       const float* bp = buf + TM * KP + (wn * 64 + (lane & 31)) * KP + 2 * (lane >> 5);
+      // fragments of k-pair q+1 are read before the MFMAs of pair q issue (explicit double buffer)
+      float2 a_c[MI], b_c[2];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a_c[i] = *reinterpret_cast<const float2*>(ap + i * 32 * KP);
+      b_c[0] = *reinterpret_cast<const float2*>(bp);
+      b_c[1] = *reinterpret_cast<const float2*>(bp + 32 * KP);
 #pragma unroll
       for (int q = 0; q < KC / 4; ++q) {
-        float2 a[MI];
+        float2 a_n[MI], b_n[2];
+        const int qn = (q + 1 < KC / 4) ? q + 1 : q;  // the last iteration re-reads its own pair (unused)
 #pragma unroll
-        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const float2*>(ap + i * 32 * KP + 4 * q);
-        const float2 b0 = *reinterpret_cast<const float2*>(bp + 4 * q);
-        const float2 b1 = *reinterpret_cast<const float2*>(bp + 32 * KP + 4 * q);
+        for (int i = 0; i < MI; ++i) a_n[i] = *reinterpret_cast<const float2*>(ap + i * 32 * KP + 4 * qn);
+        b_n[0] = *reinterpret_cast<const float2*>(bp + 4 * qn);
+        b_n[1] = *reinterpret_cast<const float2*>(bp + 32 * KP + 4 * qn);
+        __builtin_amdgcn_sched_barrier(0);  // keep these reads ABOVE the MFMAs they are meant to hide under
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b0.x, acc[i][0], 0, 0, 0);
-          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b1.x, acc[i][1], 0, 0, 0);
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[i].x, b_c[0].x, acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[i].x, b_c[1].x, acc[i][1], 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b0.y, acc[i][0], 0, 0, 0);
-          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b1.y, acc[i][1], 0, 0, 0);
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[i].y, b_c[0].y, acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[i].y, b_c[1].y, acc[i][1], 0, 0, 0);
         }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a_c[i] = a_n[i];
+        b_c[0] = b_n[0];
+        b_c[1] = b_n[1];
       }
       if (!lastc || more) commit(smem + (size_t)(sel ^ 1) * (TM + TN) * KP);
       __syncthreads();
