@@ -338,7 +338,10 @@ class WeightedMSEFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return ctx.dd * g, None, None, None, None, None
+        d = ctx.dd * g
+        # pred = x_last + delta: in an autoregressive rollout x_last is the previous step's prediction and
+        # carries the same gradient as delta (src/train.py:202-204)
+        return d, (d if ctx.needs_input_grad[1] else None), None, None, None, None
 
 
 class Gather2Fn(torch.autograd.Function):

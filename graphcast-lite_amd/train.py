@@ -316,12 +316,14 @@ class TrainStep:
     kernel launches, which keeps it GPU-bound on hosts with slow launch paths."""
 
     def __init__(self, model, lr=1e-3, lat_weights=None, channel_mask=None, spatial_mask=None, use_residual=True,
-                 ar_steps=1, world_size=1, use_graph=None, split_finish=None):
+                 ar_steps=1, world_size=1, use_graph=None, split_finish=None, static_channels=None,
+                 forcing_channels=None):
         self.model = model
         self.flat = FlatParams(model)
         self.opt = FusedAdam(self.flat, lr=lr)
         self.lat_weights, self.channel_mask, self.spatial_mask = lat_weights, channel_mask, spatial_mask
         self.use_residual, self.ar_steps, self.world = use_residual, ar_steps, world_size
+        self.static_channels, self.forcing_channels = static_channels, forcing_channels
         if use_graph is None:
             use_graph = os.environ.get("GCL_NO_GRAPH", "0") in ("0", "")
         self.use_graph = bool(use_graph)
@@ -332,7 +334,8 @@ class TrainStep:
     def _fwd_bwd(self, X, y, threshold=0.0, epoch=0, batch_num=1):
         self.flat.zero_grad()
         loss = batch_loss(self.model, X, y, threshold, epoch, batch_num, self.lat_weights, self.ar_steps,
-                          self.channel_mask, self.spatial_mask, None, None, self.use_residual)
+                          self.channel_mask, self.spatial_mask, self.static_channels, self.forcing_channels,
+                          self.use_residual)
         loss.backward()
         return loss.detach()
 

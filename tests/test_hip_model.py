@@ -545,3 +545,41 @@ def test_sparse_gat_train_step_graph_replay_follows_pruning():
     assert s1.use_graph and s1._graph is not None  # re-captured after the prune
     for (n_, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
         assert rel(p, q) < 1e-6, n_
+
+
+@pytest.mark.parametrize("name", ["baseline", "region_krsk_cds_19f"])
+def test_autoregressive_training_step_parity(name):
+    """The AR inner loop of training (src/train.py:186-231): 3 rollout steps with static and forcing channel
+    overwrites, loss averaged over the steps, gradients through the whole rollout - against the oracle;
+    and the same step through TrainStep (graph replay) against eager."""
+    from graphcast_lite_amd.train import TrainStep, batch_loss, get_lat_weights
+
+    cfg, m, o = make_pair(name, [1, 2])
+    G, F = m._num_grid_nodes, cfg.data.num_features_used
+    g = torch.Generator().manual_seed(21)
+    X = torch.randn(2, G, 2 * F, generator=g)
+    y = torch.randn(2, G, 3 * F, generator=g) * 0.5
+    static, forcing = [F - 1], [0, 2]
+    lw, lwd = T.get_lat_weights(32, 64), get_lat_weights(32, 64, DEV)
+    lo = T.train_step_loss(o, X, y, lat_weights=lw, ar_steps=3, static_channels=static, forcing_channels=forcing)
+    lo.backward()
+    lh = batch_loss(m, X.to(DEV), y.to(DEV), lat_weights=lwd, current_ar_steps=3, static_channels=static,
+                    forcing_channels=forcing)
+    lh.backward()
+    assert rel(lh, lo) < 1e-5
+    og = dict(o.named_parameters())
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in og.values() if p.grad is not None)))
+    for n_, p in m.named_parameters():
+        if og[n_].grad is None:
+            continue
+        d = float((p.grad.double().cpu() - og[n_].grad.double()).norm())
+        assert d <= 2e-4 * float(og[n_].grad.double().norm()) + 1e-6 * gn, (n_, d)
+
+    _, m1, _ = make_pair(name, [1, 2])
+    _, m2, _ = make_pair(name, [1, 2])
+    kw = dict(lr=1e-3, lat_weights=lwd, ar_steps=3, static_channels=static, forcing_channels=forcing)
+    s1, s2 = TrainStep(m1, use_graph=True, **kw), TrainStep(m2, use_graph=False, **kw)
+    for i in range(4):
+        l1, l2 = s1(X.to(DEV), y.to(DEV)), s2(X.to(DEV), y.to(DEV))
+        assert rel(l1, l2) < 1e-6, i
+    assert s1.use_graph and s1._graph is not None
