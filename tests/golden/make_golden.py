@@ -17,6 +17,8 @@ Outputs (data only - arrays and numbers, no reference source text):
   tests/golden/graph_64x32_L0.npz      full edge lists + static feats, mesh levels [0]
   tests/golden/graph_64x32_L12.npz     same, levels [1,2]
   tests/golden/graph_summary.json      shapes, sha256 prefixes and degree histograms, cfg A and B
+  tests/golden/graph_regional.json     the same summaries for region-pruned meshes (incl. a box across lon 0/360)
+                                       and a flat (per-node coordinates) grid
   tests/golden/loss_vectors.npz        (pred, target, lat_w) -> loss, lat weights, threshold schedule
   tests/golden/config_parse.json       selected fields of the parsed reference configs
 """
@@ -135,6 +137,52 @@ def main():
         )
     with open(os.path.join(HERE, "graph_summary.json"), "w") as fh:
         json.dump(summary, fh, indent=1, sort_keys=True)
+
+    # --- regional (pruned-mesh) and flat-grid layouts (src/main.py:146-173, src/models.py:507-538) ----
+    from src.config import GraphBuildingConfig
+    from src.mesh.create_mesh import prune_mesh_to_region
+
+    regional = {}
+    for tag, (bounds, buf, levels, flat) in {
+        "krsk_61x41_L35": ((50.0, 60.0, 85.0, 100.0), 15.0, [3, 5], False),
+        "wrap_31x21_L24": ((-10.0, 10.0, 350.0, 365.0), 10.0, [2, 4], False),   # box crossing lon 0/360
+        "flat_700_L23": ((40.0, 55.0, 20.0, 45.0), 12.0, [2, 3], True),
+    }.items():
+        lat_min, lat_max, lon_min, lon_max = bounds
+        if flat:  # one (lat, lon) pair per node, irregular spacing
+            rs = np.random.RandomState(3)
+            lats = (lat_min + (lat_max - lat_min) * rs.rand(700)).astype(np.float32)
+            lons = (lon_min + (lon_max - lon_min) * rs.rand(700)).astype(np.float32)
+            G = 700
+        else:
+            nlon_r, nlat_r = [int(v) for v in tag.split("_")[1].split("x")]
+            lats = np.linspace(lat_min, lat_max, nlat_r).astype(np.float32)
+            lons = (np.linspace(lon_min, lon_max, nlon_r) % 360).astype(np.float32)
+            G = nlat_r * nlon_r
+        gc = GraphBuildingConfig(grid2mesh_edge_creation="radius", mesh2grid_edge_creation="contained",
+                                 grid2mesh_radius_query=0.6, mesh_levels=levels)
+        meshes = prune_mesh_to_region(ref["hier"](splits=max(levels)), lat_min, lat_max, lon_min, lon_max, buffer_deg=buf)
+        finest = meshes[-1]
+        mlat, mlon = ref["latlon"](finest_mesh=finest)
+        enc, gfeat, mfeat = ref["enc"](
+            grid_node_lats=lats, grid_node_longs=lons, mesh_node_lats=mlat.astype(np.float32),
+            mesh_node_longs=mlon.astype(np.float32), mesh=finest, graph_building_config=gc, num_grid_nodes=G,
+            flat_grid=flat)
+        proc, efeat = ref["proc"](meshes=meshes, mesh_levels=levels, mesh_node_lats=mlat.astype(np.float32),
+                                  mesh_node_longs=mlon.astype(np.float32))
+        regional[tag] = dict(
+            bounds=list(bounds), buffer=buf, levels=levels, flat=flat, G=int(G), M=int(len(finest.vertices)),
+            faces_per_level=[int(len(m.faces)) for m in meshes], faces_hash=_h(finest.faces),
+            vertices_checksum=float(np.abs(finest.vertices.astype(np.float64)).sum()),
+            E_G2M=int(enc.shape[1]), E_M=int(proc.shape[1]), enc_hash=_h(enc), proc_hash=_h(proc),
+            grid_static_hash=_h(gfeat), mesh_static_hash=_h(mfeat), edge_feat_hash=_h(efeat),
+            grid_static_checksum=float(np.abs(gfeat.numpy().astype(np.float64)).sum()),
+            mesh_static_checksum=float(np.abs(mfeat.numpy().astype(np.float64)).sum()),
+            edge_feat_checksum=float(np.abs(efeat.numpy().astype(np.float64)).sum()),
+            grid_lats=[float(v) for v in lats[:3]], grid_lons=[float(v) for v in lons[:3]],
+        )
+    with open(os.path.join(HERE, "graph_regional.json"), "w") as fh:
+        json.dump(regional, fh, indent=1, sort_keys=True)
 
     # --- loss / schedule vectors ---------------------------------------------------------
     from src.train import get_lat_weights, update_attention_threshold, weighted_mse_loss, build_boundary_mask

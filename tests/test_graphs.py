@@ -149,3 +149,49 @@ def test_host_csr_edge_cases(lib_built):
     # single directed edge 0->1: deg=[1,2], y1 = x0/sqrt2 + x1/2, y0 = x0
     r = hip.build_csr_host(torch.tensor([[0], [1]]), 2, hip.GRAPH_GCN)
     np.testing.assert_allclose(r["w"].numpy(), [1.0, 2 ** -0.5, 0.5], rtol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["krsk_61x41_L35", "wrap_31x21_L24", "flat_700_L23"])
+def test_regional_and_flat_layouts_match_reference(tag):
+    """Region-pruned mesh hierarchy (src/mesh/create_mesh.py:225-300, used through
+    WeatherPrediction(region_bounds=..., mesh_buffer=...), src/models.py:507-512) and the flat-grid
+    encoder graph (create_encoding_graph(flat_grid=True)) against fixtures produced by the reference's code."""
+    import json
+
+    from graphcast_lite_amd.config import GraphBuildingConfig
+    from graphcast_lite_amd.create_graphs import create_encoding_graph, create_processing_graph
+    from graphcast_lite_amd.mesh import (get_hierarchy_of_triangular_meshes_for_sphere, get_mesh_lat_long,
+                                         prune_mesh_to_region)
+
+    with open(os.path.join(GOLDEN, "graph_regional.json")) as fh:
+        s = json.load(fh)[tag]
+    lat_min, lat_max, lon_min, lon_max = s["bounds"]
+    if s["flat"]:
+        rs = np.random.RandomState(3)
+        lats = (lat_min + (lat_max - lat_min) * rs.rand(700)).astype(np.float32)
+        lons = (lon_min + (lon_max - lon_min) * rs.rand(700)).astype(np.float32)
+    else:
+        nlon_r, nlat_r = [int(v) for v in tag.split("_")[1].split("x")]
+        lats = np.linspace(lat_min, lat_max, nlat_r).astype(np.float32)
+        lons = (np.linspace(lon_min, lon_max, nlon_r) % 360).astype(np.float32)
+    assert [float(v) for v in lats[:3]] == s["grid_lats"] and [float(v) for v in lons[:3]] == s["grid_lons"]
+    gc = GraphBuildingConfig(grid2mesh_edge_creation="radius", mesh2grid_edge_creation="contained",
+                             grid2mesh_radius_query=0.6, mesh_levels=s["levels"])
+    meshes = prune_mesh_to_region(get_hierarchy_of_triangular_meshes_for_sphere(splits=max(s["levels"])),
+                                  lat_min, lat_max, lon_min, lon_max, buffer_deg=s["buffer"])
+    finest = meshes[-1]
+    assert len(finest.vertices) == s["M"] and [len(m.faces) for m in meshes] == s["faces_per_level"]
+    assert _h(finest.faces) == s["faces_hash"]
+    assert abs(np.abs(finest.vertices.astype(np.float64)).sum() - s["vertices_checksum"]) < 1e-4
+    mlat, mlon = get_mesh_lat_long(finest)
+    enc, gfeat, mfeat = create_encoding_graph(
+        grid_node_lats=lats, grid_node_longs=lons, mesh_node_lats=mlat.astype(np.float32),
+        mesh_node_longs=mlon.astype(np.float32), mesh=finest, graph_building_config=gc, num_grid_nodes=s["G"],
+        flat_grid=s["flat"])
+    proc, efeat = create_processing_graph(meshes=meshes, mesh_levels=s["levels"], mesh_node_lats=mlat.astype(np.float32),
+                                          mesh_node_longs=mlon.astype(np.float32))
+    assert (enc.shape[1], proc.shape[1]) == (s["E_G2M"], s["E_M"])
+    assert _h(enc) == s["enc_hash"] and _h(proc) == s["proc_hash"]
+    assert abs(np.abs(gfeat.numpy().astype(np.float64)).sum() - s["grid_static_checksum"]) < 1e-3
+    assert abs(np.abs(mfeat.numpy().astype(np.float64)).sum() - s["mesh_static_checksum"]) < 1e-3
+    assert abs(np.abs(efeat.numpy().astype(np.float64)).sum() - s["edge_feat_checksum"]) < 1e-2

@@ -583,3 +583,42 @@ def test_autoregressive_training_step_parity(name):
         l1, l2 = s1(X.to(DEV), y.to(DEV)), s2(X.to(DEV), y.to(DEV))
         assert rel(l1, l2) < 1e-6, i
     assert s1.use_graph and s1._graph is not None
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_regional_model_parity(flat):
+    """The regional arrangement of the region_* experiments (src/main.py:146-173): a 61x41 grid over
+    lat 50-60 / lon 85-100 on a mesh pruned to the region (+15 deg), regular or flat (per-node coordinates),
+    InteractionNet processor - forward and gradients against the oracle."""
+    from graphcast_lite_amd.models import WeatherPrediction
+    from graphcast_lite_amd.train import batch_loss
+
+    cfg = experiment("region_krsk_cds_19f", mesh_levels=[3, 5])
+    cfg.pipeline.processor.gcn.num_message_passing_steps = 2
+    lats, lons = np.linspace(50, 60, 41).astype(np.float32), np.linspace(85, 100, 61).astype(np.float32)
+    if flat:
+        lon2, lat2 = np.meshgrid(lons, lats)
+        coords = (lat2.reshape(-1), lon2.reshape(-1))
+    else:
+        coords = (lats, lons)
+    torch.manual_seed(5)
+    m = WeatherPrediction(coords, cfg.graph, cfg.pipeline, cfg.data, torch.device(DEV),
+                          region_bounds=(50.0, 60.0, 85.0, 100.0), mesh_buffer=15.0, flat_grid=flat)
+    assert m._num_grid_nodes == 61 * 41 and m._num_mesh_nodes == 259
+    o = omodel.WeatherPrediction(
+        cfg.pipeline, cfg.data, num_grid_nodes=m._num_grid_nodes, num_mesh_nodes=m._num_mesh_nodes,
+        encoding_graph=m.encoding_graph.cpu(), processing_graph=m.processing_graph.cpu(),
+        decoding_graph=m.decoding_graph.cpu(), init_grid_features=m.init_grid_features.cpu(),
+        init_mesh_features=m.init_mesh_features.cpu(), processing_edge_features=m._processing_edge_features.cpu())
+    o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()}, strict=True)
+    X, y = data(cfg, m._num_grid_nodes, 2)
+    assert rel(m(X.to(DEV)), o(X)) < 1e-5
+    T.train_step_loss(o, X, y).backward()
+    batch_loss(m, X.to(DEV), y.to(DEV)).backward()
+    og = dict(o.named_parameters())
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in og.values() if p.grad is not None)))
+    for n_, p in m.named_parameters():
+        if og[n_].grad is None:
+            continue
+        d = float((p.grad.double().cpu() - og[n_].grad.double()).norm())
+        assert d <= 1e-4 * float(og[n_].grad.double().norm()) + 1e-6 * gn, (n_, d)
