@@ -34,7 +34,8 @@ def _interaction_pipeline(F, steps, enc_hidden, dec_mlp_hidden, dec_mlp_out, dec
     }
 
 
-GRID = {"wb2_512x256_sparse_gat": (256, 512), "wb2_512x256_19f_ar_v2": (256, 512), "region_krsk_cds_19f": (32, 64), "baseline": (32, 64), "attention": (32, 64), "attention_h4": (32, 64), "sparse_attention": (32, 64),
+GRID = {"wb2_64x32_15f": (32, 64), "wb2_64x32_ar_15f_4obs_4pred": (32, 64), "demo_low": (32, 64),
+        "wb2_512x256_sparse_gat": (256, 512), "wb2_512x256_19f_ar_v2": (256, 512), "region_krsk_cds_19f": (32, 64), "baseline": (32, 64), "attention": (32, 64), "attention_h4": (32, 64), "sparse_attention": (32, 64),
         "wb2_512x256_19f_ar": (256, 512)}
 
 
@@ -56,6 +57,23 @@ def experiment(name: str, mesh_levels=None) -> ExperimentConfig:
         pipe = _pipeline([128, 128], 128, "conv_gcn", [128] * 4, [128, 64], 64, [64, 64], 19)
         graph.update(grid2mesh_radius_query=0.6, mesh_levels=mesh_levels or [4, 6])
         data.update(num_features_used=19)
+    elif name in ("wb2_64x32_15f", "wb2_64x32_ar_15f_4obs_4pred"):  # 4 observed steps, 96-wide GCN stacks
+        pipe = _pipeline([64, 64], 64, "conv_gcn", [96, 96, 96], [64, 64], 64, [48, 48], 15)
+        pipe["encoder"]["gcn"].update(hidden_dims=[96, 96], output_dim=96)
+        pipe["processor"]["gcn"].update(output_dim=96)
+        graph.update(grid2mesh_radius_query=0.65, mesh_levels=mesh_levels or [4, 6])
+        data.update(num_features_used=15, obs_window_used=4,
+                    pred_window_used=4 if name.endswith("4pred") else 1)
+    elif name == "demo_low":  # the smallest config: widths 16 / 32, 3 variables, one mesh level
+        pipe = {
+            "encoder": {"mlp": {"mlp_hidden_dims": [16], "output_dim": 32, "use_layer_norm": True, "layer_norm_mode": "node"},
+                        "gcn": {"layer_type": "conv_gcn", "hidden_dims": [32], "output_dim": 32}},
+            "processor": {"gcn": {"layer_type": "conv_gcn", "hidden_dims": [32], "output_dim": 32}},
+            "decoder": {"mlp": {"mlp_hidden_dims": [32], "output_dim": 32, "use_layer_norm": False},
+                        "gcn": {"layer_type": "conv_gcn", "hidden_dims": [16], "output_dim": 3}},
+        }
+        graph.update(mesh_levels=mesh_levels or [3])
+        data.update(num_features_used=3)
     elif name == "wb2_512x256_sparse_gat":
         # BASELINE.json configs[4]: the 512x256 encoder / decoder with ONE SparseGATConv(128 -> 128, H = 1) + LN as
         # processor.  The reference has no config file for this combination.

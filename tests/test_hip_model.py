@@ -44,9 +44,9 @@ def make_pair(name, levels, nlat=32, nlon=64, seed=42):
 
 def data(cfg, G, B, seed=1234):
     g = torch.Generator().manual_seed(seed)
-    F = cfg.data.num_features_used
-    X = torch.randn(B, G, 2 * F, generator=g)
-    y = X[..., F:] + 0.1 * torch.randn(B, G, F, generator=g)
+    F, obs = cfg.data.num_features_used, cfg.data.obs_window_used
+    X = torch.randn(B, G, obs * F, generator=g)
+    y = X[..., (obs - 1) * F:] + 0.1 * torch.randn(B, G, F, generator=g)
     return X, y
 
 
@@ -54,7 +54,9 @@ def data(cfg, G, B, seed=1234):
                                            ("attention", [3, 5], 2), ("attention_h4", [1, 2], 2),
                                            ("sparse_attention", [1, 2], 2), ("wb2_512x256_19f_ar", [1, 2], 2),
                                            ("region_krsk_cds_19f", [1, 2], 2), ("region_krsk_cds_19f", [2, 3], 1),
-                                           ("wb2_512x256_19f_ar_v2", [1, 2], 1)])
+                                           ("wb2_512x256_19f_ar_v2", [1, 2], 1),
+                                           ("wb2_64x32_15f", [1, 2], 2), ("wb2_64x32_15f", [4, 6], 1),
+                                           ("demo_low", [3], 3)])
 def test_forward_backward_parity(name, levels, B):
     from graphcast_lite_amd.train import batch_loss, get_lat_weights
 
