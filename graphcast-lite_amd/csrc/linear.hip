@@ -352,8 +352,14 @@ template <int NO, int NC, bool VEC>
 __global__ __launch_bounds__(256, (DwCfg<NO, NC>::min_waves)) void dw_mfma_kernel(
     const float* __restrict__ dY, int64_t lddy, const float* __restrict__ X, int64_t ldx,
     const float* __restrict__ in_slope, float* __restrict__ part, float* __restrict__ dbpart, int64_t rows,
-    int32_t Fin, int32_t Fout, int64_t rows_per_block, int32_t akind) {
+    int32_t Fin_all, int32_t Fout, int64_t rows_per_block, int32_t akind, int64_t tile_stride) {
   using Cfg = DwCfg<NO, NC>;
+  // blockIdx.y = 128-column chunk of the input features (one launch covers a whole wide dW)
+  const int ct = blockIdx.y;
+  X += (int64_t)ct * 128;
+  part += (int64_t)ct * tile_stride;
+  if (ct != 0) dbpart = nullptr;
+  const int Fin = (Fin_all - ct * 128) < 128 ? (Fin_all - ct * 128) : 128;
   constexpr int WO = Cfg::WO, WC = Cfg::WC, TO = Cfg::TO, TC = Cfg::TC, PRE = Cfg::PRE;
   constexpr int FoutP = Cfg::FoutP, FinP = Cfg::FinP;
   extern __shared__ __align__(16) float smem[];
@@ -1275,19 +1281,22 @@ extern "C" int gcl_linear_bwd_dx(const float* dy, int64_t lddy, const float* W, 
                           in_slope, d_in_slope, nullptr, 0, dx, lddx, rows, Fin, Fout, ws, ws_bytes, stream);
 }
 
-// one (<=256 x <=128) block of dW
+// dW for <= 256 outputs and any number of inputs: ONE launch whose grid.y walks the 128-column input
+// chunks (dY is re-read once per chunk), then one partial reduction per chunk
 static int dw_block(const float* dy, int64_t lddy, const float* x, int64_t ldx, int akind, const float* in_slope,
                     float* dW, int64_t lddw, float* db, int64_t rows, int32_t Fin, int32_t Fout, int32_t accumulate,
                     void* ws, hipStream_t st) {
-  const int NC = (Fin + 31) / 32;
+  const int nct = (Fin + 127) / 128;                      // input chunks
+  const int NC = nct > 1 ? 4 : (Fin + 31) / 32;           // slabs of the (widest) chunk
   int NO = (Fout + 31) / 32;
   NO = NO <= 2 ? NO : NO <= 4 ? 4 : 8;  // instantiated: 1, 2, 4, 8 (extra slabs are zero)
   const int FinP = NC * 32, FoutP = NO * 32;
   const size_t lds = (size_t)kDwRT * (FoutP + FinP) * sizeof(float);
   // one partial tile per block: no more blocks than are resident at once (wide tiles fill the LDS
-  // with one block per CU, and their partials are what the reduction then has to read back)
-  const int64_t cap = lds > 80 * 1024 ? gcl::kNumCU : kDwBlocks;
-  int64_t nblk = gcl::cdiv(rows, 2 * kDwRT);  // at least two steps per block
+  // with one block per CU, and their partials are what the reduction then has to read back), and
+  // at least four 64-row steps per block so the load pipeline has something to hide under
+  const int64_t cap = (lds > 80 * 1024 ? gcl::kNumCU : kDwBlocks) / nct;
+  int64_t nblk = gcl::cdiv(rows, (nct > 1 ? 4 : 2) * kDwRT);
   if (nblk > cap) nblk = cap;
   if (nblk < 1) nblk = 1;
   int64_t rpb = gcl::cdiv(rows, nblk);
@@ -1295,14 +1304,15 @@ static int dw_block(const float* dy, int64_t lddy, const float* x, int64_t ldx, 
   nblk = rows > 0 ? gcl::cdiv(rows, rpb) : 1;
   float* part = (float*)ws;
   float* dbpart = part + (size_t)kDwBlocks * FoutP * FinP;
+  const int64_t tile_stride = (int64_t)nblk * FoutP * FinP;
   const bool vec = (lddy % 4 == 0) && (ldx % 4 == 0) && gcl::aligned16(dy) && gcl::aligned16(x);
 #define GCL_DW3(NO_, NC_, V_)                                                                                     \
   do {                                                                                                            \
     auto kern = dw_mfma_kernel<NO_, NC_, V_>;                                                                     \
     { static bool lds_set = false;                                                                          \
       if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, dy, lddy, x, ldx, in_slope, part,          \
-                       db ? dbpart : nullptr, rows, Fin, Fout, rpb, akind);                                       \
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)nct), dim3(256), lds, st, dy, lddy, x, ldx, in_slope, part, \
+                       db ? dbpart : nullptr, rows, Fin, Fout, rpb, akind, tile_stride);                          \
   } while (0)
 #define GCL_DW2(NO_, NC_)              \
   do {                                 \
@@ -1328,10 +1338,14 @@ static int dw_block(const float* dy, int64_t lddy, const float* x, int64_t ldx, 
 #undef GCL_DW2
 #undef GCL_DW3
   GCL_CHECK_LAUNCH();
-  int rc = gcl::launch_reduce_parts(part, (int)nblk, (int64_t)FoutP * FinP, FinP, dW, (int)lddw, Fout, Fin, accumulate, st);
-  if (rc) return rc;
-  if (db) rc = gcl::launch_reduce_parts(dbpart, (int)nblk, (int64_t)FoutP, FoutP, db, Fout, 1, Fout, accumulate, st);
-  return rc;
+  for (int ct = 0; ct < nct; ++ct) {
+    const int fi = Fin - ct * 128 < 128 ? Fin - ct * 128 : 128;
+    int rc = gcl::launch_reduce_parts(part + ct * tile_stride, (int)nblk, (int64_t)FoutP * FinP, FinP, dW + ct * 128,
+                                      (int)lddw, Fout, fi, accumulate, st);
+    if (rc) return rc;
+  }
+  if (db) return gcl::launch_reduce_parts(dbpart, (int)nblk, (int64_t)FoutP, FoutP, db, Fout, 1, Fout, accumulate, st);
+  return GCL_OK;
 }
 
 extern "C" int gcl_dense_bwd_dw(const float* dy, int64_t lddy, const float* x, int64_t ldx, int32_t act,
@@ -1344,15 +1358,12 @@ extern "C" int gcl_dense_bwd_dw(const float* dy, int64_t lddy, const float* x, i
   if (int rc = check_act("dense_bwd_dw", act, slope)) return rc;
   GCL_CHECK_ARG(ws && ws_bytes >= gcl_linear_bwd_ws_bytes(rows, Fin, Fout), "dense_bwd_dw: workspace too small");
   const float* sl = act == GCL_ACT_PRELU ? slope : nullptr;
-  // wide layers: blocks of <= 256 outputs x <= 128 inputs (dY is re-read once per input block)
+  // wide layers: <= 256 outputs per launch, every 128-column input chunk inside it (grid.y)
   for (int o0 = 0; o0 < Fout; o0 += 256) {
     const int fo = Fout - o0 < 256 ? Fout - o0 : 256;
-    for (int c0 = 0; c0 < Fin; c0 += 128) {
-      const int fi = Fin - c0 < 128 ? Fin - c0 : 128;
-      int rc = dw_block(dy + o0, lddy, x + c0, ldx, act, sl, dW + (int64_t)o0 * lddw + c0, lddw,
-                        (db && c0 == 0) ? db + o0 : nullptr, rows, fi, fo, accumulate, ws, (hipStream_t)stream);
-      if (rc) return rc;
-    }
+    int rc = dw_block(dy + o0, lddy, x, ldx, act, sl, dW + (int64_t)o0 * lddw, lddw, db ? db + o0 : nullptr, rows, Fin,
+                      fo, accumulate, ws, (hipStream_t)stream);
+    if (rc) return rc;
   }
   return GCL_OK;
 }
