@@ -896,6 +896,23 @@ __global__ __launch_bounds__(256, 3) void linear_bwd_fused64_kernel(
   if (part_slope && tid == 0) part_slope[blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
 }
 
+// Wt[c][o] = W[o*ldw + c]  (o < R, c < Cn): lets the dX contraction read its weights k-contiguously
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ W, int64_t ldw, float* __restrict__ Wt,
+                                                        int32_t R, int32_t Cn) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int o0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = ty; i < 32; i += 8) {
+    const int o = o0 + i, c = c0 + tx;
+    tile[i][tx] = (o < R && c < Cn) ? W[(int64_t)o * ldw + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, o = o0 + tx;
+    if (c < Cn && o < R) Wt[(int64_t)c * R + o] = tile[tx][i];
+  }
+}
+
 __global__ void reduce_scalar_kernel(const double* __restrict__ part, int32_t nparts, float* __restrict__ out) {
   // single wave; fixed order => deterministic
   double s = 0.0;
@@ -1262,9 +1279,22 @@ extern "C" int gcl_dense_bwd_dx(const float* dy, int64_t lddy, const float* W, i
   if (!addend && ldw == Fin && (use_valu() || panel_fits(Fout, Fin, vec_x, true, (ldw % 4 == 0) && gcl::aligned16(W))))
     rc = launch_linear<EPI_DX>(dy, lddy, nullptr, W, Fin, 1, nullptr, dx, lddx, rows, Fout, Fin, zz, ldz, sl, slope_part,
                                &nparts, st, act);
-  else
-    rc = launch_gemm<EPI_DX>(dy, lddy, act, sl, W, ldw, 1, nullptr, dx, lddx, rows, Fout, Fin, zz, ldz, addend, ldadd,
-                             slope_part, &nparts, st);
+  else {
+    // the tile kernel stages k-contiguous weight rows twice as cheaply as strided ones: transpose W
+    // (a few hundred KB) into the workspace first when there is room
+    const size_t off = (slope_parts_cap(rows, Fin) * sizeof(double) + 255) & ~(size_t)255;
+    const size_t need = off + (size_t)Fin * Fout * sizeof(float);
+    if (ws && ws_bytes >= need && gcl::aligned16(ws) && Fout % 4 == 0 && rows >= 4096) {
+      float* Wt = reinterpret_cast<float*>(static_cast<char*>(ws) + off);
+      hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)gcl::cdiv(Fin, 32), (unsigned)gcl::cdiv(Fout, 32)), dim3(256), 0,
+                         st, W, ldw, Wt, Fout, Fin);
+      rc = launch_gemm<EPI_DX>(dy, lddy, act, sl, Wt, Fout, 0, nullptr, dx, lddx, rows, Fout, Fin, zz, ldz, addend,
+                               ldadd, slope_part, &nparts, st);
+    } else {
+      rc = launch_gemm<EPI_DX>(dy, lddy, act, sl, W, ldw, 1, nullptr, dx, lddx, rows, Fout, Fin, zz, ldz, addend, ldadd,
+                               slope_part, &nparts, st);
+    }
+  }
   if (rc) return rc;
   if (slope_part && nparts > 0) {
     hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(64), 0, st, slope_part, nparts, d_slope);
