@@ -164,11 +164,10 @@ __global__ __launch_bounds__(256) void agg_kernel(const int32_t* __restrict__ ro
       if (VS) {
         // streamed-out rows are not re-read by this kernel: keep them from evicting the gathered
         // rows of h out of the XCD's L2 (non-temporal store)
-        if (nt_store) {
-          __builtin_nontemporal_store(a0, yp);
-          __builtin_nontemporal_store(a1, yp + 1);
-          __builtin_nontemporal_store(a2, yp + 2);
-          __builtin_nontemporal_store(a3, yp + 3);
+        if (nt_store) {  // ONE 16-byte non-temporal store per lane (four dword stores write partial sectors)
+          typedef float v4f __attribute__((ext_vector_type(4)));
+          v4f v = {a0, a1, a2, a3};
+          __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(yp));
         } else {
           *reinterpret_cast<float4*>(yp) = make_float4(a0, a1, a2, a3);
         }

@@ -163,11 +163,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict_
     float* yp = Y + (int64_t)b * bsy + (int64_t)row * ldy + c0;
     float o0 = a0 * s, o1 = a1 * s, o2 = a2 * s, o3 = a3 * s;
     if (bias) { o0 += bias[c0]; o1 += bias[c0 + 1]; o2 += bias[c0 + 2]; o3 += bias[c0 + 3]; }
-    if ((ldy & 3) == 0 && (bsy & 3) == 0 && ((uintptr_t)Y & 15) == 0) {
-      *reinterpret_cast<float4*>(yp) = make_float4(o0, o1, o2, o3);
-    } else {
-      yp[0] = o0; yp[1] = o1; yp[2] = o2; yp[3] = o3;
-    }
+    *reinterpret_cast<float4*>(yp) = make_float4(o0, o1, o2, o3);  // 16-B rows: checked on the host
   }
 }
 
@@ -349,11 +345,7 @@ __global__ __launch_bounds__(256) void gat_bwd_src_kernel(const int32_t* __restr
   a2 += sde * att_s[c0 + 2] + dd * att_d[c0 + 2];
   a3 += sde * att_s[c0 + 3] + dd * att_d[c0 + 3];
   float* o = dH + (int64_t)b * bsdh + (int64_t)row * lddh + c0;
-  if ((lddh & 3) == 0 && (bsdh & 3) == 0 && ((uintptr_t)dH & 15) == 0) {
-    *reinterpret_cast<float4*>(o) = make_float4(a0, a1, a2, a3);
-  } else {
-    o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
-  }
+  *reinterpret_cast<float4*>(o) = make_float4(a0, a1, a2, a3);  // 16-B rows: checked on the host
   if ((l % lph) == 0) das[((int64_t)b * n + row) * H + h] = sde;
 }
 
@@ -448,6 +440,7 @@ extern "C" int gcl_gat_fwd(const gcl_graph_t* g, const float* h, int64_t ldh, in
   GCL_CHECK_ARG(h && att_src && att_dst && a_src && a_dst && y, "gat_fwd: null argument");
   GCL_CHECK_ARG(B > 0 && ldh >= H * C && ldy >= C, "gat_fwd: bad shape");
   GCL_CHECK_ARG((ldh % 4) == 0 && (bsh % 4) == 0 && gcl::aligned16(h), "gat_fwd: h must be 16-B aligned with ld %% 4 == 0");
+  GCL_CHECK_ARG((ldy % 4) == 0 && (bsy % 4) == 0 && gcl::aligned16(y), "gat_fwd: y must be 16-B aligned with ld %% 4 == 0");
   GCL_CHECK_ARG(g->kind == GCL_GRAPH_GAT, "gat_fwd: graph was not created with GCL_GRAPH_GAT");
   hipStream_t st = (hipStream_t)stream;
   const int rpb = (64 / lpr) * 4;
@@ -494,6 +487,7 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
                 "gat_bwd: null argument");
   GCL_CHECK_ARG(B > 0 && ldh >= H * C && lddh >= H * C && lddy >= C, "gat_bwd: bad shape");
   GCL_CHECK_ARG((ldh % 4) == 0 && (bsh % 4) == 0 && gcl::aligned16(h), "gat_bwd: h must be 16-B aligned with ld %% 4 == 0");
+  GCL_CHECK_ARG((lddh % 4) == 0 && (bsdh % 4) == 0 && gcl::aligned16(dh), "gat_bwd: dh must be 16-B aligned with ld %% 4 == 0");
   GCL_CHECK_ARG(g->kind == GCL_GRAPH_GAT, "gat_bwd: graph was not created with GCL_GRAPH_GAT");
   GCL_CHECK_ARG(bsdy == (int64_t)g->n * lddy || B == 1, "gat_bwd: dy must be row-contiguous across the batch");
   GCL_CHECK_ARG(ws && ws_bytes >= gcl_gat_bwd_ws_bytes(g->e, g->n, B, H, C), "gat_bwd: workspace too small");

@@ -36,12 +36,15 @@ __device__ __forceinline__ void store4(float* p, int c0, int F, bool vec, float 
 }
 
 // y = (x - mean) * rstd * gamma + beta ; stats[row] = (mean, rstd)
-template <int LPR>
+// V: every row access is a clean 16-byte one (compile-time, so the compiler emits dwordx4 instead of
+// merging the vector and the scalar path into dwordx3 + dword accesses)
+template <int LPR, bool V>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ X, int64_t ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, float* __restrict__ Y, int64_t ldy,
                                                      float* __restrict__ stats, int64_t rows, int32_t F, int32_t vx,
                                                      int32_t vy) {
+  if (V) vx = vy = 1;
   constexpr int RPB = (64 / LPR) * 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
@@ -70,13 +73,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ X
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma;  partial dgamma/dbeta per block
-template <int LPR>
+template <int LPR, bool V>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dY, int64_t lddy,
                                                      const float* __restrict__ X, int64_t ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ stats,
                                                      float* __restrict__ dX, int64_t lddx, float* __restrict__ part,
                                                      int64_t rows, int32_t F, int32_t FP, int32_t vdy, int32_t vx,
                                                      int32_t vdx) {
+  if (V) vdy = vx = vdx = 1;
   constexpr int RPW = 64 / LPR;
   constexpr int RPB = RPW * 4;
   __shared__ float red[RPB][LPR * 4 * 2 + 1];
@@ -120,10 +124,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 // column sums: part[block][FP]
-template <int LPR>
+template <int LPR, bool V>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t ldx,
                                                      float* __restrict__ part, int64_t rows, int32_t F, int32_t FP,
                                                      int32_t vx) {
+  if (V) vx = 1;
   constexpr int RPW = 64 / LPR;
   constexpr int RPB = RPW * 4;
   __shared__ float red[RPB][LPR * 4 + 1];
@@ -177,9 +182,13 @@ extern "C" int gcl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
   int64_t nb = gcl::cdiv(rows, rpb);
   if (nb > 8192) nb = 8192;
   const int vx = vec_ok(x, ldx, F), vy = vec_store_ok(y, ldy, F);
-#define CALL(L)                                                                                              \
-  hipLaunchKernelGGL((ln_fwd_kernel<L>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, \
-                     beta, eps, y, ldy, stats, rows, F, vx, vy)
+#define CALL(L)                                                                                                  \
+  if (vx && vy)                                                                                                  \
+    hipLaunchKernelGGL((ln_fwd_kernel<L, true>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, ldx,  \
+                       gamma, beta, eps, y, ldy, stats, rows, F, vx, vy);                                        \
+  else                                                                                                           \
+    hipLaunchKernelGGL((ln_fwd_kernel<L, false>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, ldx, \
+                       gamma, beta, eps, y, ldy, stats, rows, F, vx, vy)
   GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
   GCL_CHECK_LAUNCH();
@@ -208,9 +217,13 @@ extern "C" int gcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
   if (nb > kNormBlocks) nb = kNormBlocks;
   float* part = (float*)ws;
   const int vdy = vec_ok(dy, lddy, F), vx = vec_ok(x, ldx, F), vdx = vec_store_ok(dx, lddx, F);
-#define CALL(L)                                                                                                   \
-  hipLaunchKernelGGL((ln_bwd_kernel<L>), dim3((unsigned)nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma, stats, dx, \
-                     lddx, part, rows, F, FP, vdy, vx, vdx)
+#define CALL(L)                                                                                                  \
+  if (vdy && vx && vdx)                                                                                          \
+    hipLaunchKernelGGL((ln_bwd_kernel<L, true>), dim3((unsigned)nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma,  \
+                       stats, dx, lddx, part, rows, F, FP, vdy, vx, vdx);                                        \
+  else                                                                                                           \
+    hipLaunchKernelGGL((ln_bwd_kernel<L, false>), dim3((unsigned)nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma, \
+                       stats, dx, lddx, part, rows, F, FP, vdy, vx, vdx)
   GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
   GCL_CHECK_LAUNCH();
@@ -237,8 +250,9 @@ extern "C" int gcl_colsum(const float* x, int64_t ldx, int64_t rows, int32_t F, 
   if (nb > kNormBlocks) nb = kNormBlocks;
   float* part = (float*)ws;
   const int vx = vec_ok(x, ldx, F);
-#define CALL(L) \
-  hipLaunchKernelGGL((colsum_kernel<L>), dim3((unsigned)nb), dim3(256), 0, st, x, ldx, part, rows, F, FP, vx)
+#define CALL(L)                                                                                                     \
+  if (vx) hipLaunchKernelGGL((colsum_kernel<L, true>), dim3((unsigned)nb), dim3(256), 0, st, x, ldx, part, rows, F, FP, vx); \
+  else hipLaunchKernelGGL((colsum_kernel<L, false>), dim3((unsigned)nb), dim3(256), 0, st, x, ldx, part, rows, F, FP, vx)
   GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
   GCL_CHECK_LAUNCH();
