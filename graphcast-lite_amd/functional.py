@@ -241,11 +241,17 @@ class GATLayerFn(torch.autograd.Function):
         dh2 = dh.view(B * n, -1)
         inp = ctx.x3.view(B * n, -1)
         sl = slope.detach() if slope is not None else None
-        if G.dst[1] is not None:
-            hip.linear_bwd_dw(dh2, inp, sl, G.dst[1], None, G.acc[1], act=ctx.act)
         dx = None
-        if ctx.needs_input_grad[0]:
-            dx = hip.linear_bwd_dx(dh2, W.detach(), inp, sl, G.dst[0] if sl is not None else None, act=ctx.act)
+        if G.dst[1] is not None and ctx.needs_input_grad[0]:
+            # one launch for dx (with the activation's derivative), dW and the slope gradient
+            dx = hip.linear_bwd_all(dh2, W.detach(), inp, sl, G.dst[0] if sl is not None else None, G.dst[1], None, None,
+                                    G.acc[1], act=ctx.act)
+        else:
+            if G.dst[1] is not None:
+                hip.linear_bwd_dw(dh2, inp, sl, G.dst[1], None, G.acc[1], act=ctx.act)
+            if ctx.needs_input_grad[0]:
+                dx = hip.linear_bwd_dx(dh2, W.detach(), inp, sl, G.dst[0] if sl is not None else None, act=ctx.act)
+        if dx is not None:
             dx = dx.view(B, n, -1)
             if ctx.squeeze:
                 dx = dx[0]
