@@ -122,14 +122,19 @@ def _p(t: Optional[torch.Tensor]):
 
 
 _ws = {}
+_ws_retired = []  # outgrown buffers stay allocated: kernels inside a captured hipGraph may still point at them
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only per-device scratch buffer (uint8)."""
+    """Grow-only per-device scratch buffer (uint8).  Grows geometrically and never frees the buffers
+    it outgrows (a replayed hipGraph keeps using the one that was current at capture time)."""
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     cur = _ws.get(key)
     if cur is None or cur.numel() < nbytes:
-        cur = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=f"cuda:{key}")
+        size = max(int(nbytes), 1 << 20, 2 * cur.numel() if cur is not None else 0)
+        if cur is not None:
+            _ws_retired.append(cur)
+        cur = torch.empty(size, dtype=torch.uint8, device=f"cuda:{key}")
         _ws[key] = cur
     return cur
 

@@ -52,15 +52,23 @@ class _GraphCache:
     def __init__(self, capacity: int = 32):
         self._d = OrderedDict()
         self._cap = capacity
+        # While a hipGraph is being captured the handles it uses are appended here, so that the owner
+        # of the captured graph keeps them alive even after the LRU evicts them (a replay would
+        # otherwise read freed CSR arrays).
+        self.pin = None
 
     def get(self, edge_index: torch.Tensor, n: int, kind: int) -> hip.Graph:
         key = (id(edge_index), edge_index._version, tuple(edge_index.shape), int(n), kind)
         hit = self._d.get(key)
         if hit is not None:
             self._d.move_to_end(key)
+            if self.pin is not None:
+                self.pin.append(hit)
             return hit[1]
         g = hip.Graph(edge_index, n, kind)
         self._d[key] = (edge_index, g)  # keep the tensor alive so its id cannot be reused
+        if self.pin is not None:
+            self.pin.append(self._d[key])
         if len(self._d) > self._cap:
             self._d.popitem(last=False)
         return g

@@ -89,10 +89,16 @@ class CapturedRollout:
             try:
                 self._sX = X.clone()
                 self._sy = y.clone() if y is not None else None
+                from . import models as _models
+
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self._out = self._eager(self._sX, self._sy)
-                self._graph = g
+                _models._graphs.pin = pinned = []  # keep the CSR handles of the captured kernels alive
+                try:
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self._out = self._eager(self._sX, self._sy)
+                finally:
+                    _models._graphs.pin = None
+                self._graph, self._pinned = g, pinned
             except Exception as e:  # capture is an optimisation, never a requirement
                 print(f"[CapturedRollout] hipGraph capture unavailable ({type(e).__name__}: {str(e)[:200]}); staying eager",
                       flush=True)

@@ -350,13 +350,19 @@ class TrainStep:
 
     def _capture(self, X, y):
         self._sX, self._sy = X.clone(), y.clone()
+        from . import models as _models
+
         g = torch.cuda.CUDAGraph()
-        # thread_local: other threads of the process (the RCCL watchdog) may touch the runtime meanwhile
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            self._sloss = self._fwd_bwd(self._sX, self._sy)
-            if not self.split_finish:
-                self._finish()
-        self._graph = g
+        _models._graphs.pin = pinned = []  # CSR handles the captured kernels point into
+        try:
+            # thread_local: other threads of the process (the RCCL watchdog) may touch the runtime meanwhile
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._sloss = self._fwd_bwd(self._sX, self._sy)
+                if not self.split_finish:
+                    self._finish()
+        finally:
+            _models._graphs.pin = None
+        self._graph, self._pinned = g, pinned
 
     def _replay(self):
         self._graph.replay()
