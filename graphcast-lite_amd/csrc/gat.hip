@@ -179,10 +179,20 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const int32_t* __restr
                                                           const float* __restrict__ a_s, const float* __restrict__ a_d,
                                                           const float* __restrict__ alpha, float* __restrict__ de,
                                                           float* __restrict__ dad, int32_t n, int64_t Ep, int32_t B,
-                                                          int32_t H, int32_t C, int32_t nRB) {
+                                                          int32_t H, int32_t C, int32_t nRB, int32_t xcd_map) {
   constexpr int RPW = 64 / LPR, RPB = RPW * 4;
   constexpr int EL = LPR < gcl::kEll ? LPR : gcl::kEll;
-  const int b = blockIdx.x / nRB, rb = blockIdx.x % nRB;
+  // all row blocks of a sample on ONE XCD (blocks are dealt round-robin): its h rows stay in that L2
+  int b, rb;
+  if (xcd_map) {
+    const int slot = blockIdx.x >> 3;
+    b = (blockIdx.x & 7) + 8 * (slot / nRB);
+    rb = slot % nRB;
+  } else {
+    b = blockIdx.x / nRB;
+    rb = blockIdx.x % nRB;
+  }
+  if (b >= B) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
   const int gbase = sub * LPR;
@@ -275,10 +285,19 @@ __global__ __launch_bounds__(256) void gat_bwd_src_kernel(const int32_t* __restr
                                                           const float* __restrict__ att_d, float* __restrict__ das,
                                                           float* __restrict__ dH, int64_t lddh, int64_t bsdh,
                                                           int32_t n, int64_t Ep, int32_t B, int32_t H, int32_t C,
-                                                          int32_t nRB, int32_t vdy) {
+                                                          int32_t nRB, int32_t vdy, int32_t xcd_map) {
   constexpr int RPW = 64 / LPR, RPB = RPW * 4;
   constexpr int EL = LPR < gcl::kEll ? LPR : gcl::kEll;
-  const int b = blockIdx.x / nRB, rb = blockIdx.x % nRB;
+  int b, rb;
+  if (xcd_map) {
+    const int slot = blockIdx.x >> 3;
+    b = (blockIdx.x & 7) + 8 * (slot / nRB);
+    rb = slot % nRB;
+  } else {
+    b = blockIdx.x / nRB;
+    rb = blockIdx.x % nRB;
+  }
+  if (b >= B) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
   const int gbase = sub * LPR;
@@ -499,18 +518,19 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
   float* cs_ws = part + (size_t)kGatBlocks * 2 * H * C;
   const int rpb = (64 / lpr) * 4;
   const int32_t nRB = (int32_t)gcl::cdiv(g->n, rpb);
-  const unsigned nb = (unsigned)((int64_t)B * nRB);
+  const int xcd_map = B >= 8 ? 1 : 0;
+  const unsigned nb = (unsigned)(xcd_map ? (int64_t)8 * gcl::cdiv(B, 8) * nRB : (int64_t)B * nRB);
   const int vdy = (lddy % 4 == 0) && (bsdy % 4 == 0) && (C % 4 == 0) && gcl::aligned16(dy);
 #define CALL(L)                                                                                                    \
   hipLaunchKernelGGL((gat_bwd_dst_kernel<L>), dim3(nb), dim3(256), 0, st, g->rowptr, g->col, g->ecol, dy, lddy,     \
-                     bsdy, h, ldh, bsh, a_src, a_dst, alpha, de, dad, g->n, g->e, B, H, C, nRB)
+                     bsdy, h, ldh, bsh, a_src, a_dst, alpha, de, dad, g->n, g->e, B, H, C, nRB, xcd_map)
   GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
   GCL_CHECK_LAUNCH();
 #define CALL(L)                                                                                                       \
   hipLaunchKernelGGL((gat_bwd_src_kernel<L>), dim3(nb), dim3(256), 0, st, g->trowptr, g->tcol, g->tslot, g->tecol,    \
                      g->teslot, dy, lddy, bsdy, alpha, de, dad, att_src, att_dst, das, dh, lddh, bsdh, g->n, g->e, B, \
-                     H, C, nRB, vdy)
+                     H, C, nRB, vdy, xcd_map)
   GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
   GCL_CHECK_LAUNCH();
