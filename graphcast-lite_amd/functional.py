@@ -128,17 +128,34 @@ class GCNStackFn(torch.autograd.Function):
         slope_t = slope_p.detach() if slope_p is not None else getattr(owner, "const_slope", None)
         ps = []  # pre-activation outputs of every conv
         cur = x3
+        pad_last = None
         for k in range(L):
             W, b = params[2 * k].detach(), params[2 * k + 1].detach()
             Fout = W.shape[0]
             ldh = (Fout + 3) // 4 * 4  # padded scratch so the gather can use 16-B loads
+            if k == L - 1 and ldh != Fout and not has_ln:
+                # An output width that is not a multiple of 4 (33 or 19 variables) would push this layer and
+                # its whole backward onto scalar memory accesses.  Run it ldh wide instead, with zero
+                # weight rows / bias entries for the extra columns (they stay exactly 0), and return
+                # the first Fout columns as a view.
+                Wp = W.new_zeros(ldh, W.shape[1])
+                Wp[:Fout].copy_(W)
+                bp = b.new_zeros(ldh)
+                bp[:Fout].copy_(b)
+                h = hip.linear_fwd(cur.reshape(B * n, -1), Wp, None, slope_t if k > 0 else None,
+                                   act=akind if k > 0 else hip.ACT_NONE)
+                p = hip.aggregate(graph, h.view(B, n, ldh), bp)
+                ps.append(p)
+                cur = p[..., :Fout]
+                pad_last = (ldh, Fout, Wp)
+                continue
             h = hip.linear_fwd(cur.view(B * n, -1), W, None, slope_t if k > 0 else None, ld_out=ldh,
                                act=akind if k > 0 else hip.ACT_NONE)
             h3 = torch.as_strided(h, (B, n, Fout), (n * ldh, ldh, 1))
             p = hip.aggregate(graph, h3, b)
             ps.append(p)
             cur = p
-        ctx.akind, ctx.slope_t = akind, slope_t
+        ctx.akind, ctx.slope_t, ctx.pad_last = akind, slope_t, pad_last
         out, stats = cur, None
         if has_ln:
             o2, stats = hip.layernorm_fwd(cur.view(B * n, -1), params[-2].detach(), params[-1].detach(), eps)
@@ -167,14 +184,30 @@ class GCNStackFn(torch.autograd.Function):
         dsl = G.dst[si] if params[si] is not None else None
         slope_t, akind = ctx.slope_t, ctx.akind
         dx = None
-        if G.dst[2 * L - 1] is not None:  # bias of the last conv: its dp comes from outside this stack
-            hip.colsum(dp.reshape(B * n, -1), G.dst[2 * L - 1], G.acc[2 * L - 1])
+        pad = ctx.pad_last
+        if pad is not None:  # widen the incoming gradient to the padded width (extra columns 0)
+            Fp, Fo, Wp = pad
+            dpp = dy3.new_zeros(B, n, Fp)
+            dpp[..., :Fo].copy_(dy3)
+            dp = dpp
+        bi_last = 2 * L - 1
+        if G.dst[bi_last] is not None:  # bias of the last conv: its dp comes from outside this stack
+            if pad is None:
+                hip.colsum(dp.reshape(B * n, -1), G.dst[bi_last], G.acc[bi_last])
+            else:
+                tmp = hip.colsum(dp.view(B * n, -1), dp.new_empty(pad[0]), False)[:pad[1]]
+                G.dst[bi_last].add_(tmp) if G.acc[bi_last] else G.dst[bi_last].copy_(tmp)
         for k in range(L - 1, -1, -1):
             W = params[2 * k].detach()
             wi = 2 * k
             inp = (ctx.x3 if k == 0 else ps[k - 1]).view(B * n, -1)
             dh2 = hip.aggregate(graph, dp, None, transpose=True).view(B * n, -1)
             dW = G.dst[wi] if G.dst[wi] is not None else torch.zeros_like(params[wi])
+            padded = pad is not None and k == L - 1
+            if padded:  # gradient of the padded weight goes to a scratch, its first Fout rows to the parameter
+                W, dW_real, acc_real = pad[2], dW, G.acc[wi]
+                dW = torch.zeros_like(W)
+                G.acc[wi] = False
             if k > 0:
                 # one fused launch: dp_{k-1} (with PReLU'), dW_k, d(slope) and the bias gradient of
                 # conv k-1 (= column sums of dp_{k-1})
@@ -184,6 +217,9 @@ class GCNStackFn(torch.autograd.Function):
                 hip.linear_bwd_dw(dh2, inp, None, dW, None, G.acc[wi])
                 if ctx.needs_input_grad[0]:
                     dx = hip.linear_bwd_dx(dh2, W, None, None, None).view(B, n, -1)
+            if padded:
+                G.acc[wi] = acc_real
+                dW_real.add_(dW[:pad[1]]) if acc_real else dW_real.copy_(dW[:pad[1]])
         if dx is not None and ctx.squeeze:
             dx = dx[0]
         return (dx, None, None, None, None, None) + G.out()
