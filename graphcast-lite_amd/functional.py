@@ -142,12 +142,21 @@ class GCNStackFn(torch.autograd.Function):
                 Wp[:Fout].copy_(W)
                 bp = b.new_zeros(ldh)
                 bp[:Fout].copy_(b)
-                h = hip.linear_fwd(cur.reshape(B * n, -1), Wp, None, slope_t if k > 0 else None,
-                                   act=akind if k > 0 else hip.ACT_NONE)
-                p = hip.aggregate(graph, h.view(B, n, ldh), bp)
+                if hip.gcn_layer_fusable(graph, cur, W.shape[1], ldh):
+                    p = hip.gcn_layer_fwd(graph, cur, akind if k > 0 else hip.ACT_NONE, slope_t if k > 0 else None, Wp, bp)
+                else:
+                    h = hip.linear_fwd(cur.reshape(B * n, -1), Wp, None, slope_t if k > 0 else None,
+                                       act=akind if k > 0 else hip.ACT_NONE)
+                    p = hip.aggregate(graph, h.view(B, n, ldh), bp)
                 ps.append(p)
                 cur = p[..., :Fout]
                 pad_last = (ldh, Fout, Wp)
+                continue
+            if hip.gcn_layer_fusable(graph, cur, W.shape[1], Fout):
+                # one kernel: gather-aggregate the activated input rows, then the dense transform
+                p = hip.gcn_layer_fwd(graph, cur, akind if k > 0 else hip.ACT_NONE, slope_t if k > 0 else None, W, b)
+                ps.append(p)
+                cur = p
                 continue
             h = hip.linear_fwd(cur.view(B * n, -1), W, None, slope_t if k > 0 else None, ld_out=ldh,
                                act=akind if k > 0 else hip.ACT_NONE)

@@ -68,6 +68,7 @@ _SIGNATURES = {
                                    _vp, C.c_size_t, _vp]),
     "gcl_dense_bwd_dw": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp,
                                    C.c_size_t, _vp]),
+    "gcl_gcn_layer_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "gcl_segment_reduce": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "gcl_edge_combine": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i32, _i64, _i32, _vp]),
     "gcl_act_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
@@ -576,3 +577,25 @@ def window_pack(series, t0, mean, std, C: int, obs: int, pred: int):
     _check(lib().gcl_window_pack(series.data_ptr(), T, n_lon, n_lat, Ct, t0.data_ptr(), _p(mean), _p(std), C, obs, pred,
                                  _p(X), _p(Y), B, _stream()))
     return X, Y
+
+
+def gcn_layer_fusable(graph: Graph, x3, Fin: int, Fout: int) -> bool:
+    """Should this layer go through gcl_gcn_layer_fwd?  Opt-in (GCL_FUSED_GCN=1): on MI355X the one-kernel
+    layer measured SLOWER than linear_fwd + aggregate (4.72 vs 4.05 ms per baseline step):
+    its LDS tile + weight panel leave 12 waves per CU where the gather wants 32."""
+    import os
+    if os.environ.get("GCL_FUSED_GCN", "0") in ("0", ""):
+        return False
+    return (Fin % 4 == 0 and 4 <= Fin <= 64 and 1 <= Fout <= 64 and graph.max_in_degree <= 64 and graph.kind == GRAPH_GCN
+            and x3.stride(2) == 1 and x3.stride(1) % 4 == 0 and x3.stride(0) % 4 == 0 and x3.data_ptr() % 16 == 0)
+
+
+def gcn_layer_fwd(graph: Graph, x3, act, slope, W, bias):
+    """y = (A_hat act(x)) W^T + bias for x3 [B, n, Fin] -> [B, n, Fout] (one kernel)."""
+    B, n, Fin = x3.shape
+    assert n == graph.n
+    Fout = W.shape[0]
+    y = torch.empty(B, n, Fout, dtype=torch.float32, device=x3.device)
+    _check(lib().gcl_gcn_layer_fwd(graph.handle, _p(x3), x3.stride(1), x3.stride(0), int(act), _p(slope), _p(W.contiguous()),
+                                   _p(bias), _p(y), Fout, n * Fout, B, Fin, Fout, _stream()))
+    return y

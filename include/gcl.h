@@ -255,6 +255,15 @@ int gcl_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t coun
 int gcl_copy_rows(const float* src, int64_t lds, int64_t bss, float* dst, int64_t ldd, int64_t bsd,
                   int32_t B, int32_t rows, int32_t F, gcl_stream_t stream);
 
+/* One whole GCNConv layer forward (src/models.py:419) in one kernel, aggregate-first:
+ *   y[b,i,:] = (sum_{e in row i} w_e act(x[b, col_e, :])) W^T + bias
+ * - the same value as gcl_linear_fwd followed by gcl_aggregate up to fp32 rounding (the aggregation is
+ * linear), without the intermediate h in memory.  Fin % 4 == 0, Fin, Fout <= 64, x rows 16-B aligned,
+ * graphs without heavy rows (in-degree <= 64); other shapes use the two calls. */
+int gcl_gcn_layer_fwd(const gcl_graph_t* g, const float* x, int64_t ldx, int64_t bsx, int32_t act,
+                      const float* slope, const float* W /*[Fout,Fin]*/, const float* bias, float* y,
+                      int64_t ldy, int64_t bsy, int32_t B, int32_t Fin, int32_t Fout, gcl_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Edge-wise glue of the InteractionNet processor (src/models.py:206-236); csrc/interaction.hip.
  * Index arrays are int32 device arrays; rows are [.., D] with D % 4 == 0 and 16-B alignment.
