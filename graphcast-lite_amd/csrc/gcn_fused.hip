@@ -5,12 +5,14 @@
 // i.e. aggregate first, transform second - the same result as PyG's transform-then-aggregate up to
 // fp32 rounding (the aggregation is linear), but without the intermediate h = act(x) W^T ever going
 // to memory: per layer one gathered read of x and one write of y instead of read x / write h /
-// gathered read h / write y.  A block owns 128 rows of one sample: each wave gathers its 32 rows
-// (the aggregation kernel's ELL-prefix + CSR-tail scheme, 16 lanes x float4 per row) into its own
-// LDS tile, then multiplies the tile by the weight panel that the block staged once
-// (v_mfma_f32_32x32x2_f32, exact fp32), adds the bias and streams the rows out.
-// Used for Fin, Fout <= 64, Fin % 4 == 0 and graphs without heavy rows (in-degree <= 64); other
-// shapes keep the two-kernel path (gcl_linear_fwd + gcl_aggregate).
+// gathered read h / write y.  A block owns 32 rows of one sample: each of its 4 waves gathers 8 rows
+// (two batches of the aggregation kernel's ELL-prefix + CSR-tail scheme, 16 lanes x float4 per row)
+// into the block's LDS tile, then waves 0 and 1 multiply the tile by one 32-column slab each of the
+// weight panel the block staged (v_mfma_f32_32x32x2_f32, exact fp32), add the bias and store.
+// For Fin, Fout <= 64, Fin % 4 == 0 and graphs without heavy rows (in-degree <= 64).
+// STATUS: correct (tests/test_hip_ops.py::test_gcn_layer_fwd_one_kernel) but not yet faster than
+// gcl_linear_fwd + gcl_aggregate on MI355X (4.46 vs 4.01 ms per baseline step; a 128-row-per-block
+// version: 4.72), so the Python side only uses it when GCL_FUSED_GCN=1.
 #include "common.h"
 
 namespace {
@@ -29,7 +31,7 @@ __device__ __forceinline__ void buf_st1(__amdgpu_buffer_rsrc_t r, unsigned off, 
 }
 
 constexpr int kKP = 66;   // LDS row stride (floats): even, kKP/2 odd -> conflict-free 8-byte fragment reads
-constexpr int kTR = 128;  // rows per block (32 per wave)
+constexpr int kTR = 32;   // rows per block: 8 per wave (two gather batches), one shared 32-row MFMA tile
 
 template <int EW>
 __global__ __launch_bounds__(256) void gcn_fwd_fused_kernel(
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(256) void gcn_fwd_fused_kernel(
     const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy, int64_t bsy, int32_t n, int32_t B,
     int32_t Fin, int32_t Fout, int32_t nRB, int32_t xcd_map) {
   __shared__ __align__(16) float Wl[64 * kKP];
-  __shared__ __align__(16) float Xt[4][32 * kKP];
+  __shared__ __align__(16) float Xt[32 * kKP];
   constexpr int LPR = 16;
   const int bid = blockIdx.x;
   int b, rb;
@@ -62,8 +64,9 @@ __global__ __launch_bounds__(256) void gcn_fwd_fused_kernel(
   const int cc = cactive ? c0 : 0;  // inactive channel lanes re-read channel 0 and contribute zeros
   const float slope = (akind == gcl::kActPrelu && slope_p) ? *slope_p : 1.f;
   const float* __restrict__ Xb = X + (int64_t)b * bsx;
-  const int row0 = rb * kTR + wave * 32;
-  float* Xw = Xt[wave];
+  const int row0 = rb * kTR;          // first row of the block's tile
+  const int wrow0 = row0 + wave * 8;  // first row this wave gathers
+  float* Xw = Xt;
 
   auto ld4 = [&](int j, float& x0, float& x1, float& x2, float& x3) {
     const float4 v = *reinterpret_cast<const float4*>(Xb + (int64_t)j * ldx + cc);
@@ -82,14 +85,14 @@ __global__ __launch_bounds__(256) void gcn_fwd_fused_kernel(
   };
   int start, end, cj;
   float wj;
-  meta(row0 + sub, start, end, cj, wj);
+  meta(wrow0 + sub, start, end, cj, wj);
 
 #pragma unroll 1
-  for (int it = 0; it < 8; ++it) {
-    const int row = row0 + it * 4 + sub;
+  for (int it = 0; it < 2; ++it) {
+    const int row = wrow0 + it * 4 + sub;
     int nstart = 0, nend = 0, ncj = 0;
     float nwj = 0.f;
-    if (it + 1 < 8) meta(row + 4, nstart, nend, ncj, nwj);  // next batch's metadata, in flight during this one
+    if (it + 1 < 2) meta(row + 4, nstart, nend, ncj, nwj);  // next batch's metadata, in flight during this one
     const int deg = end - start;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     {
@@ -131,47 +134,38 @@ __global__ __launch_bounds__(256) void gcn_fwd_fused_kernel(
       }
     }
     const bool live = (row < n) && cactive;
-    float2* d = reinterpret_cast<float2*>(Xw + (it * 4 + sub) * kKP + c0);
+    float2* d = reinterpret_cast<float2*>(Xw + (wave * 8 + it * 4 + sub) * kKP + c0);
     d[0] = make_float2(live ? a0 : 0.f, live ? a1 : 0.f);
     d[1] = make_float2(live ? a2 : 0.f, live ? a3 : 0.f);
     start = nstart; end = nend; cj = ncj; wj = nwj;
   }
   __syncthreads();  // weight panel staged by all waves; each wave's own tile complete
 
-  f32x16 acc0, acc1;
+  if (wave >= 2) return;  // waves 0 and 1 each multiply the 32-row tile by one 32-column slab of W
+  f32x16 acc;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    acc0[r] = 0.f;
-    acc1[r] = 0.f;
-  }
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const float* ap = Xw + (lane & 31) * kKP + 2 * (lane >> 5);
-  const float* bp = Wl + (lane & 31) * kKP + 2 * (lane >> 5);
+  const float* bp = Wl + (wave * 32 + (lane & 31)) * kKP + 2 * (lane >> 5);
   const int nq = (Fin + 3) >> 2;
   for (int q = 0; q < nq; ++q) {
     const float2 a = *reinterpret_cast<const float2*>(ap + 4 * q);
     const float2 b0 = *reinterpret_cast<const float2*>(bp + 4 * q);
-    const float2 b1 = *reinterpret_cast<const float2*>(bp + 32 * kKP + 4 * q);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc, 0, 0, 0);
   }
 
-  // epilogue: lane owns output column j of each 32-column slab and 16 of the wave's 32 rows
+  // epilogue: lane owns output column j of this wave's slab and 16 of the tile's 32 rows
   const int nr = (n - row0) < 32 ? (n - row0) : 32;
   const int64_t wbytes = nr > 0 ? ((int64_t)(nr - 1) * ldy + Fout) * 4 : 0;
   const __amdgpu_buffer_rsrc_t ry = make_rsrc(Y + (int64_t)b * bsy + (int64_t)row0 * ldy, wbytes);
+  const int j = wave * 32 + (lane & 31);
+  const bool jok = j < Fout;
+  const float bj = (bias && jok) ? bias[j] : 0.f;
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int j = s * 32 + (lane & 31);
-    const bool jok = j < Fout;
-    const float bj = (bias && jok) ? bias[j] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rr = d_row(r, lane);
-      const float v = (s == 0 ? acc0[r] : acc1[r]) + bj;
-      buf_st1(ry, jok ? (unsigned)((rr * ldy + j) * 4) : kOOB, v);
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int rr = d_row(r, lane);
+    buf_st1(ry, jok ? (unsigned)((rr * ldy + j) * 4) : kOOB, acc[r] + bj);
   }
 }
 

@@ -581,8 +581,8 @@ def window_pack(series, t0, mean, std, C: int, obs: int, pred: int):
 
 def gcn_layer_fusable(graph: Graph, x3, Fin: int, Fout: int) -> bool:
     """Should this layer go through gcl_gcn_layer_fwd?  Opt-in (GCL_FUSED_GCN=1): on MI355X the one-kernel
-    layer measured SLOWER than linear_fwd + aggregate (4.72 vs 4.05 ms per baseline step):
-    its LDS tile + weight panel leave 12 waves per CU where the gather wants 32."""
+    layer measured SLOWER than linear_fwd + aggregate (4.46 vs 4.01 ms per baseline step):
+    its LDS tile + weight panel cap the waves per CU below what the gather wants."""
     import os
     if os.environ.get("GCL_FUSED_GCN", "0") in ("0", ""):
         return False
