@@ -185,6 +185,48 @@ def train_epoch(model, train_dataloader, optimiser, loss_fn, device, threshold, 
     return total / max(len(train_dataloader), 1)
 
 
+def spatial_corr(pred: torch.Tensor, true: torch.Tensor, exclude_channels=None) -> float:
+    """Spatial anomaly correlation (src/train.py:114-130): per feature, the mean over nodes of the
+    product of the standardised fields (std unbiased, + 1e-8); per sample, then averaged."""
+    if pred.dim() == 3:
+        accs = [spatial_corr(pred[b], true[b], exclude_channels) for b in range(pred.shape[0])]
+        return sum(accs) / max(len(accs), 1)
+    p = (pred - pred.mean(dim=0, keepdim=True)) / (pred.std(dim=0, keepdim=True) + 1e-8)
+    t = (true - true.mean(dim=0, keepdim=True)) / (true.std(dim=0, keepdim=True) + 1e-8)
+    acc = (p * t).mean(dim=0)
+    if exclude_channels:
+        keep = [i for i in range(acc.shape[0]) if i not in exclude_channels]
+        if keep:
+            return acc[keep].mean().item()
+    return acc.mean().item()
+
+
+def test(model, test_dataloader, loss_fn, device, lat_weights=None, spatial_mask=None, channel_mask=None,
+         static_channels=None, forcing_channels=None, use_residual=True):
+    """One-step evaluation, same signature and return value as the reference's `test` (src/train.py:241-308):
+    (mean weighted MSE, mean spatial ACC, RMSE of the unweighted errors).  The prediction step with its
+    static / forcing carry-forward is the device-side rollout of `predict.py` (one step)."""
+    from .predict import rollout
+
+    model.eval()
+    total, accs, raw = 0.0, [], []
+    with torch.no_grad():
+        for X, y in test_dataloader:
+            y = y.squeeze(0) if y.dim() == 4 else y
+            X, y = X.to(device), y.to(device)
+            C = X.shape[-1] // model.obs_window
+            steps = y.shape[-1] // C if C > 0 else 1
+            y0 = y.view(y.shape[0], y.shape[1], steps, C)[:, :, 0, :].contiguous() if steps > 1 else y
+            outs = rollout(model, X, 1, y=y0, static_channels=static_channels, forcing_channels=forcing_channels,
+                           use_residual=use_residual)
+            total += weighted_mse_loss(outs, y0, lat_weights, channel_mask, spatial_mask).item()
+            raw.append(((outs - y0) ** 2).mean().item())
+            skip = sorted(set(static_channels or []) | set(forcing_channels or []))
+            accs.append(spatial_corr(outs, y0, exclude_channels=skip if skip else None))
+    n = max(len(raw), 1)
+    return total / max(len(test_dataloader), 1), sum(accs) / n, (sum(raw) / n) ** 0.5
+
+
 class FlatParams:
     """All trainable parameters of a module re-pointed into ONE flat fp32 buffer, with a flat
     gradient buffer whose slices are installed as `.grad` (so the backward kernels accumulate

@@ -97,3 +97,44 @@ def ar_rollout(model, X, ar_steps, y=None, static_channels=None, forcing_channel
         outs.append(step_out)
         state = torch.cat([state[:, :, 1:, :], step_out.unsqueeze(2)], dim=2)
     return torch.cat(outs, dim=-1)
+
+
+def spatial_corr(pred, true, exclude_channels=None) -> float:
+    """`src/train.py:114-130`."""
+    if pred.dim() == 3:
+        accs = [spatial_corr(pred[b], true[b], exclude_channels) for b in range(pred.shape[0])]
+        return sum(accs) / max(len(accs), 1)
+    p = (pred - pred.mean(dim=0, keepdim=True)) / (pred.std(dim=0, keepdim=True) + 1e-8)
+    t = (true - true.mean(dim=0, keepdim=True)) / (true.std(dim=0, keepdim=True) + 1e-8)
+    acc = (p * t).mean(dim=0)
+    if exclude_channels:
+        keep = [i for i in range(acc.shape[0]) if i not in exclude_channels]
+        if keep:
+            return acc[keep].mean().item()
+    return acc.mean().item()
+
+
+@torch.no_grad()
+def evaluate(model, batches, lat_weights=None, spatial_mask=None, channel_mask=None, static_channels=None,
+             forcing_channels=None, use_residual=True):
+    """The reference's `test` loop (`src/train.py:241-308`) over a list of (X, y) batches."""
+    total, accs, raw = 0.0, [], []
+    for X, y in batches:
+        C = X.shape[-1] // model.obs_window
+        steps = y.shape[-1] // C
+        y0 = y.view(y.shape[0], y.shape[1], steps, C)[:, :, 0, :] if steps > 1 else y
+        pred = model(X=X, attention_threshold=0.0)
+        if pred.dim() == 2:
+            pred = pred.unsqueeze(0)
+        x_last = X.view(X.shape[0], X.shape[1], model.obs_window, C)[:, :, -1, :]
+        outs = x_last + pred if use_residual else pred.clone()
+        for ch in static_channels or []:
+            outs[:, :, ch] = x_last[:, :, ch]
+        for ch in forcing_channels or []:
+            outs[:, :, ch] = y0[:, :, ch]
+        total += weighted_mse_loss(outs, y0, lat_weights, channel_mask, spatial_mask).item()
+        raw.append(((outs - y0) ** 2).mean().item())
+        skip = sorted(set(static_channels or []) | set(forcing_channels or []))
+        accs.append(spatial_corr(outs, y0, exclude_channels=skip if skip else None))
+    n = max(len(raw), 1)
+    return total / max(len(batches), 1), sum(accs) / n, (sum(raw) / n) ** 0.5

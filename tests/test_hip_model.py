@@ -624,3 +624,24 @@ def test_regional_model_parity(flat):
             continue
         d = float((p.grad.double().cpu() - og[n_].grad.double()).norm())
         assert d <= 1e-4 * float(og[n_].grad.double().norm()) + 1e-6 * gn, (n_, d)
+
+
+def test_evaluation_loop_matches_reference_semantics():
+    """train.test (src/train.py:241-308: one-step prediction with carry-forward, weighted MSE, spatial ACC,
+    raw RMSE) against the oracle's restatement, on batches with multi-step targets."""
+    from graphcast_lite_amd.train import get_lat_weights, test as hip_test
+
+    cfg, m, o = make_pair("baseline", [1, 2])
+    G, F = m._num_grid_nodes, cfg.data.num_features_used
+    g = torch.Generator().manual_seed(9)
+    batches = [(torch.randn(2, G, 2 * F, generator=g), torch.randn(2, G, 3 * F, generator=g)) for _ in range(3)]
+    static, forcing = [F - 1], [0, 5]
+    chan = torch.ones(F)
+    chan[F - 1] = 0.0
+    got = hip_test(m, batches, None, DEV, lat_weights=get_lat_weights(32, 64, DEV), channel_mask=chan.to(DEV),
+                   static_channels=static, forcing_channels=forcing)
+    o.eval()
+    want = T.evaluate(o, batches, lat_weights=T.get_lat_weights(32, 64), channel_mask=chan, static_channels=static,
+                      forcing_channels=forcing)
+    for a, b in zip(got, want):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (got, want)
