@@ -645,3 +645,32 @@ def test_evaluation_loop_matches_reference_semantics():
                       forcing_channels=forcing)
     for a, b in zip(got, want):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (got, want)
+
+
+@pytest.mark.parametrize("name", ["baseline", "attention", "region_krsk_cds_19f"])
+def test_step_is_bitwise_deterministic(name):
+    """No float atomics anywhere (all reductions are fixed-order two-stage ones): the same step run twice,
+    and run on a second identically seeded model, gives bit-identical outputs and gradients."""
+    from graphcast_lite_amd.train import batch_loss, get_lat_weights
+
+    cfg, m1, _ = make_pair(name, [1, 2])
+    _, m2, _ = make_pair(name, [1, 2])
+    X, y = data(cfg, m1._num_grid_nodes, 3)
+    Xd, yd, lw = X.to(DEV), y.to(DEV), get_lat_weights(32, 64, DEV)
+
+    def grads(m):
+        for p in m.parameters():
+            p.grad = None
+        loss = batch_loss(m, Xd, yd, lat_weights=lw)
+        loss.backward()
+        return loss.detach().clone(), [None if p.grad is None else p.grad.detach().clone() for p in m.parameters()]
+
+    l1, g1 = grads(m1)
+    l1b, g1b = grads(m1)
+    l2, g2 = grads(m2)
+    assert torch.equal(l1, l1b) and torch.equal(l1, l2)
+    for a, b, c in zip(g1, g1b, g2):
+        if a is None:
+            assert b is None and c is None
+            continue
+        assert torch.equal(a, b) and torch.equal(a, c)
