@@ -146,8 +146,10 @@ def main():
     # Untimed settle phase before the W official warm-up steps: a freshly acquired box can run the
     # first seconds several times slower (clock ramp / code-object and allocator warm-up).  Step until
     # three consecutive steps are within 15 % of the fastest seen (at most 60 steps / 5 s).
+    # With several ranks every step contains a collective, so all ranks must run the SAME number of
+    # steps: a fixed count there, the adaptive rule only in the single-process case.
     settle, best, streak, t_end = 0, float("inf"), 0, time.perf_counter() + 5.0
-    while settle < 60 and time.perf_counter() < t_end:
+    while settle < (12 if world > 1 else 60) and (world > 1 or time.perf_counter() < t_end):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         loss = step(X, y)
@@ -156,7 +158,7 @@ def main():
         settle += 1
         best = min(best, dt1)
         streak = streak + 1 if dt1 <= 1.15 * best else 0
-        if settle >= 5 and streak >= 3:
+        if world == 1 and settle >= 5 and streak >= 3:
             break
     for _ in range(args.warmup):
         loss = step(X, y)
@@ -186,7 +188,12 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     roof_steps, roof_ms = args.steps, None
-    if replayed:
+    roof_pass = replayed
+    if world > 1:  # the eager roofline pass contains collectives: every rank runs it if any rank needs it
+        f = torch.tensor([1.0 if replayed else 0.0], device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MAX)
+        roof_pass = bool(f.item() > 0)
+    if roof_pass:
         # Kernels replayed from a hipGraph cannot be bracketed by timing events on ROCm, so the
         # roofline kernel is timed on a few eager steps of the SAME step function right after the
         # timed region (same buffers, same launches; the rocprofv3 trace in profiles/ covers both).
@@ -275,7 +282,7 @@ def main():
         }
         if roof is not None:
             roof["measured_on"] = (f"{roof_steps} eager steps right after the timed region ({roof_ms:.2f} ms/step eager)"
-                                   if replayed else "the timed steps themselves")
+                                   if roof_pass else "the timed steps themselves")
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model, grid)
         print(json.dumps(out), flush=True)
