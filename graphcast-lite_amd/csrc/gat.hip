@@ -111,11 +111,40 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict_
     float sc[EL];
 #pragma unroll
     for (int k = 0; k < EL; ++k) jj[k] = __shfl(cj, gbase + k, 64);
-#pragma unroll
-    for (int k = 0; k < EL; ++k) sc[k] = as_b[(int64_t)jj[k] * H + h];
     float4 v[EL];
 #pragma unroll
     for (int k = 0; k < EL; ++k) v[k] = *reinterpret_cast<const float4*>(Hb + (int64_t)jj[k] * ldh + cc);
+    if (lph >= EL) {
+      // A head spans >= EL lanes: lane hl < EL of the head owns in-edge hl - ONE gathered score load,
+      // ONE exp and ONE coalesced alpha store per lane instead of EL of each; the EL softmax weights
+      // are then broadcast inside the head for the weighted sum.
+      const int hl = l % lph, hbase = gbase + (l / lph) * lph;
+      const bool mine = hl < EL && hl < deg;
+      const int jm = __shfl(cj, gbase + (hl & (EL - 1)), 64);
+      float e = mine ? leaky(as_b[(int64_t)jm * H + h] + ad) : -INFINITY;
+      float m = e;
+#pragma unroll
+      for (int off = EL >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));  // lanes 0..EL-1 of the head
+      m = __shfl(m, hbase, 64);
+      const float ex = mine ? expf(e - m) : 0.f;
+      float den = ex;
+#pragma unroll
+      for (int off = EL >> 1; off > 0; off >>= 1) den += __shfl_xor(den, off, 64);
+      den = __shfl(den, hbase, 64);
+      const float almine = ex * (1.f / (den + 1e-16f));
+      if (alpha && mine && active) alpha[((int64_t)b * Ep + start + hl) * H + h] = almine;
+#pragma unroll
+      for (int k = 0; k < EL; ++k) {
+        const float al = __shfl(almine, hbase + k, 64);
+        const bool in = k < deg;  // select, not multiply: a padded slot's row must not leak non-finite values
+        a0 += in ? al * v[k].x : 0.f;
+        a1 += in ? al * v[k].y : 0.f;
+        a2 += in ? al * v[k].z : 0.f;
+        a3 += in ? al * v[k].w : 0.f;
+      }
+    } else {
+#pragma unroll
+    for (int k = 0; k < EL; ++k) sc[k] = as_b[(int64_t)jj[k] * H + h];
     float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < EL; ++k) {
@@ -138,6 +167,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict_
       a2 += in ? al * v[k].z : 0.f;
       a3 += in ? al * v[k].w : 0.f;
       if (leader && alpha && in) alpha[((int64_t)b * Ep + start + k) * H + h] = al;
+    }
     }
   } else {
     float m = -INFINITY;
