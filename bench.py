@@ -16,9 +16,13 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
+# dmabuf IPC is the only mode this pool's driver supports (RCCL between processes needs it); the box
+# exports it already - keep it if the launcher's environment was rebuilt
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
