@@ -234,6 +234,8 @@ def linear_fwd(x, W, bias, in_slope, out=None, ld_out=None, act=None):
     if out is None:
         ld = ld_out or Fout
         out = torch.empty(rows, ld, dtype=torch.float32, device=x.device)[:, :Fout]
+    if rows == 0:
+        return out
     _check(lib().gcl_dense_fwd(_p(x), _ld(x), _act_of(act, in_slope), _p(in_slope), _p(W), W.stride(0), _p(bias), None, 0,
                                _p(out), _ld(out), rows, Fin, Fout, _stream()))
     return out
@@ -265,6 +267,8 @@ def dense_fwd(x, W, bias, act=ACT_NONE, slope=None, addend=None, out=None):
     assert W.shape[1] == Fin and W.stride(1) == 1 and x.stride(1) == 1
     if out is None:
         out = torch.empty(rows, Fout, dtype=torch.float32, device=x.device)
+    if rows == 0:  # an empty batch of rows: nothing to launch (empty tensors have no device pointer)
+        return out
     prof = DENSE_PROFILE
     prof = prof is not None and prof["rows"] == rows and prof["Fin"] == Fin and prof["Fout"] == Fout
     if prof:
@@ -285,6 +289,8 @@ def dense_bwd_dx(dy, W, z=None, act=ACT_NONE, slope=None, d_slope=None, addend=N
     assert W.shape[0] == Fout and W.stride(1) == 1
     if out is None:
         out = torch.empty(rows, Fin, dtype=torch.float32, device=dy.device)
+    if rows == 0:
+        return out
     nb = lib().gcl_linear_bwd_ws_bytes(rows, Fin, Fout)
     ws = workspace(nb, dy.device)
     _check(lib().gcl_dense_bwd_dx(_p(dy), _ld(dy), _p(W), W.stride(0), _p(z), _ld(z) if z is not None else 0, int(act),
@@ -298,6 +304,12 @@ def dense_bwd_dw(dy, x, dW, db, accumulate: bool, act=ACT_NONE, slope=None):
     rows, Fout = dy.shape
     Fin = x.shape[1]
     assert tuple(dW.shape) == (Fout, Fin) and dW.stride(1) == 1
+    if rows == 0:  # the sum over no rows: zero unless accumulating
+        if not accumulate:
+            dW.zero_()
+            if db is not None:
+                db.zero_()
+        return
     nb = lib().gcl_linear_bwd_ws_bytes(rows, Fin, Fout)
     ws = workspace(nb, dy.device)
     _check(lib().gcl_dense_bwd_dw(_p(dy), _ld(dy), _p(x), _ld(x), int(act), _p(slope), _p(dW), dW.stride(0), _p(db), rows,

@@ -493,3 +493,18 @@ def test_gcn_layer_fwd_one_kernel(hip, levels, Fin, Fout, B, act):
             continue
         got = hip.gcn_layer_fwd(gh, x.to(DEV), act, a.to(DEV) if act == 1 else None, W.to(DEV), b.to(DEV))
         assert rel(got, ref) < TOL
+
+
+def test_dense_entry_points_with_zero_rows(hip):
+    """An empty set of rows is not an error: outputs are empty, weight gradients are zero (or untouched when
+    accumulating)."""
+    x, W, b = torch.empty(0, 64, device=DEV), rnd(48, 64, seed=1).to(DEV), rnd(48, seed=2).to(DEV)
+    assert tuple(hip.dense_fwd(x, W, b).shape) == (0, 48)
+    assert tuple(hip.linear_fwd(x, W, b, None).shape) == (0, 48)
+    dy = torch.empty(0, 48, device=DEV)
+    assert tuple(hip.dense_bwd_dx(dy, W).shape) == (0, 64)
+    dW, db = torch.ones(48, 64, device=DEV), torch.ones(48, device=DEV)
+    hip.dense_bwd_dw(dy, x, dW, db, True)
+    assert (dW == 1).all() and (db == 1).all()
+    hip.dense_bwd_dw(dy, x, dW, db, False)
+    assert (dW == 0).all() and (db == 0).all()
