@@ -92,3 +92,36 @@ def create_decoding_graph(
         grid_latitude=cordinates[0], grid_longitude=cordinates[1], mesh=mesh, flat=flat_grid
     )
     return torch.from_numpy(np.stack([m_idx + num_grid_nodes, g_idx]).astype(np.int64))
+
+
+def create_product_graph(grid_lat: np.ndarray, grid_lon: np.ndarray, obs_window: int, num_k: int, graph_type: str):
+    """Time x space product graph of `WeatherPrediction._create_product_graph` (`src/models.py:707-774`):
+    a directed chain over the T observed steps, a k-nearest-neighbour graph over the (lat, lon) grid
+    points (`sklearn.neighbors.kneighbors_graph`, connectivity, no self), combined as
+        s01 (I_T (x) A_space) + s10 (A_time (x) I_N) + s11 (A_time (x) A_space)
+    with (s01, s10, s11) = (0,0,1) kronecker / (1,1,0) cartesian / (1,1,1) strong (s00 is always 0, so
+    `self_loop` has no effect there either).  Returned as `dense_to_sparse` would: the non-zero entries
+    in row-major order, row index first.  Built sparsely - the dense (T N)^2 matrix is never formed."""
+    from sklearn.neighbors import kneighbors_graph
+
+    kind = getattr(graph_type, "value", graph_type)
+    s01, s10, s11 = {"kronecker": (0, 0, 1), "cartesian": (1, 1, 0), "strong": (1, 1, 1)}[kind]
+    pts = np.array([[lat, lon] for lat in grid_lat for lon in grid_lon])
+    A = kneighbors_graph(pts, n_neighbors=num_k, mode="connectivity", include_self=False).tocoo()
+    ar, ac = A.row.astype(np.int64), A.col.astype(np.int64)
+    T, N = int(obs_window), pts.shape[0]
+    rows, cols = [], []
+    t_all, n_all = np.arange(T, dtype=np.int64), np.arange(N, dtype=np.int64)
+    if s01:  # same step, spatial neighbours
+        rows.append((t_all[:, None] * N + ar[None, :]).reshape(-1))
+        cols.append((t_all[:, None] * N + ac[None, :]).reshape(-1))
+    t_from = np.arange(T - 1, dtype=np.int64)  # temporal chain i -> i + 1
+    if s10:  # same node, next step
+        rows.append((t_from[:, None] * N + n_all[None, :]).reshape(-1))
+        cols.append(((t_from[:, None] + 1) * N + n_all[None, :]).reshape(-1))
+    if s11:  # next step, spatial neighbours
+        rows.append((t_from[:, None] * N + ar[None, :]).reshape(-1))
+        cols.append(((t_from[:, None] + 1) * N + ac[None, :]).reshape(-1))
+    r, c = np.concatenate(rows), np.concatenate(cols)
+    key = np.unique(r * (T * N) + c)  # union of the terms (all coefficients are positive), row-major order
+    return torch.from_numpy(np.stack([key // (T * N), key % (T * N)]).astype(np.int64))

@@ -34,7 +34,7 @@ def _interaction_pipeline(F, steps, enc_hidden, dec_mlp_hidden, dec_mlp_out, dec
     }
 
 
-GRID = {"wb2_64x32_15f": (32, 64), "wb2_64x32_ar_15f_4obs_4pred": (32, 64), "demo_low": (32, 64),
+GRID = {"product_graph": (32, 64), "wb2_64x32_15f": (32, 64), "wb2_64x32_ar_15f_4obs_4pred": (32, 64), "demo_low": (32, 64),
         "wb2_512x256_sparse_gat": (256, 512), "wb2_512x256_19f_ar_v2": (256, 512), "region_krsk_cds_19f": (32, 64), "baseline": (32, 64), "attention": (32, 64), "attention_h4": (32, 64), "sparse_attention": (32, 64),
         "wb2_512x256_19f_ar": (256, 512)}
 
@@ -64,6 +64,12 @@ def experiment(name: str, mesh_levels=None) -> ExperimentConfig:
         graph.update(grid2mesh_radius_query=0.65, mesh_levels=mesh_levels or [4, 6])
         data.update(num_features_used=15, obs_window_used=4,
                     pred_window_used=4 if name.endswith("4pred") else 1)
+    elif name == "product_graph":  # experiments/product_graph: 5 observed steps through a time x space GCN first
+        pipe = _pipeline([48, 48], 64, "conv_gcn", [64, 64], [64, 64], 64, [48, 48], 33)
+        pipe["product_graph"] = {"model": {"gcn": {"layer_type": "conv_gcn", "hidden_dims": [33, 33], "output_dim": 33,
+                                                   "use_layer_norm": True, "layer_norm_mode": "node"}},
+                                 "num_k": 4, "self_loop": True, "type": "strong"}
+        data.update(obs_window_used=5)
     elif name == "demo_low":  # the smallest config: widths 16 / 32, 3 variables, one mesh level
         pipe = {
             "encoder": {"mlp": {"mlp_hidden_dims": [16], "output_dim": 32, "use_layer_norm": True, "layer_norm_mode": "node"},

@@ -38,7 +38,8 @@ from .config import (
     ModelConfig,
     PipelineConfig,
 )
-from .create_graphs import create_decoding_graph, create_encoding_graph, create_processing_graph
+from .create_graphs import (create_decoding_graph, create_encoding_graph, create_processing_graph,
+                            create_product_graph)
 from .functional import (AssembleFn, EdgeLayout, GATLayerFn, Gather2Fn, GCNStackFn, GraphNormFn, InteractionNetFn,
                          LayerNormFn, MeanAggFn, MLPFn)
 from .mesh import get_hierarchy_of_triangular_meshes_for_sphere, get_mesh_lat_long, prune_mesh_to_region
@@ -481,11 +482,18 @@ class WeatherPrediction(nn.Module):
         self.num_features = data_config.num_features_used
         self.total_feature_size = self.num_features * self.obs_window
         self.use_product_graph = pipeline_config.product_graph is not None
-        if self.use_product_graph:
-            raise NotImplementedError("the product-graph pre-encoder is outside this build's hot path (SURVEY.md K13)")
+        # dynamic channels per grid node that reach the encoder (src/models.py:575-579,787-789)
+        self._dyn_size = self.num_features if self.use_product_graph else self.total_feature_size
 
         self._init_grid_properties(cordinates[0], cordinates[1], flat_grid)
         self._init_mesh_properties(graph_config, region_bounds, mesh_buffer)
+        if self.use_product_graph:  # time x space pre-encoder (src/models.py:517-524,707-774)
+            if flat_grid:
+                raise NotImplementedError("the product graph is defined on the regular lat x lon grid only")
+            pg = pipeline_config.product_graph
+            self.product_graph = create_product_graph(self._grid_lat, self._grid_lon, self.obs_window, pg.num_k,
+                                                      pg.type).to(device)
+            self.product_graph_model = Model(model_config=pg.model, input_dim=self.num_features).to(device)
         ptype = pipeline_config.processor.gcn.layer_type
         self.using_sparse_gat = ptype == GraphLayerType.SparseGATConv
         self.using_interaction_net = ptype == GraphLayerType.InteractionNet
@@ -510,7 +518,7 @@ class WeatherPrediction(nn.Module):
             num_grid_nodes=self._num_grid_nodes, flat_grid=self.flat_grid,
         )
 
-        encoder_input_dim = self.total_feature_size + self._init_feature_size
+        encoder_input_dim = self._dyn_size + self._init_feature_size
         self.encoder = Model(model_config=pipeline_config.encoder, input_dim=encoder_input_dim).to(device)
         self.processor = Model(model_config=pipeline_config.processor, input_dim=self.encoder.output_dim).to(device)
         self.decoder = Model(model_config=pipeline_config.decoder, input_dim=self.processor.output_dim).to(device)
@@ -533,6 +541,14 @@ class WeatherPrediction(nn.Module):
         self._num_mesh_nodes = len(self._finest_mesh.vertices)
         lat, lon = get_mesh_lat_long(finest_mesh=self._finest_mesh)
         self._mesh_nodes_lat, self._mesh_nodes_lon = lat.astype(np.float32), lon.astype(np.float32)
+
+    def _product_stage(self, X: torch.Tensor) -> torch.Tensor:
+        """`src/models.py:823-828`: the [G, T*F] window is VIEWED as [T*G, F] (as the reference does - a plain
+        view, no transpose), run through the GCN stack on the product graph, and the last G rows go on."""
+        G, F = self._num_grid_nodes, self.num_features
+        Xp = X.reshape(X.shape[:-2] + (G * self.obs_window, F))
+        Xp = self.product_graph_model(X=Xp, edge_index=self.product_graph)
+        return Xp[..., -G:, :]
 
     def _preprocess_input(self, grid_node_features: torch.Tensor):
         """`src/models.py:776-806` in one kernel: [grid dyn | grid static ; 0 | mesh static]."""
@@ -581,7 +597,7 @@ class WeatherPrediction(nn.Module):
         c.dec_graph = remap_d[dec].contiguous().to(device)
         c.empty_graph = torch.zeros(2, 0, dtype=torch.int64, device=device)
         c.mstat_dep = self.init_mesh_features[md.to(self.init_mesh_features.device)].contiguous()
-        Cdyn = self.total_feature_size
+        Cdyn = self._dyn_size
         inv_stat = self.init_mesh_features[mi.to(self.init_mesh_features.device)]
         c.x_inv = torch.cat([torch.zeros(Mi, Cdyn, device=device), inv_stat.to(device)], dim=1).unsqueeze(0).contiguous()
         # mesh latents [M] <- encoder compact output [G+Md] (a) | invariant rows [Mi] (b)
@@ -610,6 +626,8 @@ class WeatherPrediction(nn.Module):
         squeeze = X.dim() == 2 or (X.dim() == 3 and X.shape[0] == 1)
         X3 = X if X.dim() == 3 else X.unsqueeze(0)
         B = X3.shape[0]
+        if self.use_product_graph:
+            X3 = self._product_stage(X3)
         c = getattr(self, "_compact", None) or self._compact_setup(X3.device)
         x_c = AssembleFn.apply(X3, self.init_grid_features, c.mstat_dep)           # [B, G+Md, C]
         enc_c = self.encoder.forward(X=x_c, edge_index=c.enc_graph)                 # [B, G+Md, D]
@@ -639,6 +657,8 @@ class WeatherPrediction(nn.Module):
         G = self._num_grid_nodes
         if X.dim() == 3 and X.shape[0] == 1:
             X = X.squeeze(0)  # reference: X.squeeze() with batch 1 (src/models.py:822)
+        if self.use_product_graph:
+            X = self._product_stage(X)
         X = self._preprocess_input(grid_node_features=X)
         encoded = self.encoder.forward(X=X, edge_index=self.encoding_graph)
         grid_node_features = encoded[..., :G, :]

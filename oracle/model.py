@@ -263,7 +263,7 @@ class WeatherPrediction(nn.Module):
 
     def __init__(self, pipeline_config, data_config, *, num_grid_nodes, num_mesh_nodes, encoding_graph,
                  processing_graph, decoding_graph, init_grid_features, init_mesh_features,
-                 processing_edge_features=None):
+                 processing_edge_features=None, product_graph=None):
         super().__init__()
         self.obs_window = data_config.obs_window_used
         self.num_features = data_config.num_features_used
@@ -279,7 +279,13 @@ class WeatherPrediction(nn.Module):
         lt = pipeline_config.processor.gcn.layer_type
         self.using_sparse_gat = getattr(lt, "value", lt) == "sparse_gat"
         self.using_interaction_net = getattr(lt, "value", lt) == "interaction_net"
-        enc_in = self.total_feature_size + init_grid_features.shape[1]
+        self.use_product_graph = product_graph is not None  # src/models.py:505,517-524
+        if self.use_product_graph:
+            self.product_graph = product_graph
+            self.product_graph_model = Model(pipeline_config.product_graph.model, self.num_features)
+        dyn = self.num_features if self.use_product_graph else self.total_feature_size
+        self._dyn_size = dyn
+        enc_in = dyn + init_grid_features.shape[1]
         self.encoder = Model(pipeline_config.encoder, enc_in)
         self.processor = Model(pipeline_config.processor, self.encoder.output_dim)
         self.decoder = Model(pipeline_config.decoder, self.processor.output_dim)
@@ -290,7 +296,7 @@ class WeatherPrediction(nn.Module):
         gs = self.init_grid_features.to(grid_node_features.dtype).expand(lead + self.init_grid_features.shape)
         ms = self.init_mesh_features.to(grid_node_features.dtype).expand(lead + self.init_mesh_features.shape)
         g = torch.cat((grid_node_features, gs), dim=-1)
-        zeros = torch.zeros(lead + (self._num_mesh_nodes, self.total_feature_size), dtype=g.dtype)
+        zeros = torch.zeros(lead + (self._num_mesh_nodes, self._dyn_size), dtype=g.dtype)
         m = torch.cat((zeros, ms), dim=-1)
         return torch.cat((g, m), dim=-2)
 
@@ -298,6 +304,9 @@ class WeatherPrediction(nn.Module):
         if X.dim() == 3 and X.shape[0] == 1:
             X = X.squeeze(0)
         G = self._num_grid_nodes
+        if self.use_product_graph:  # src/models.py:823-828: a plain view to [T*G, F], GCN, last G rows
+            Xp = X.reshape(X.shape[:-2] + (G * self.obs_window, self.num_features))
+            X = self.product_graph_model(Xp, self.product_graph)[..., -G:, :]
         X = self._preprocess_input(X)
         enc = self.encoder(X, self.encoding_graph)
         grid_lat, mesh_lat = enc[..., :G, :], enc[..., G:, :]

@@ -195,3 +195,26 @@ def test_regional_and_flat_layouts_match_reference(tag):
     assert abs(np.abs(gfeat.numpy().astype(np.float64)).sum() - s["grid_static_checksum"]) < 1e-3
     assert abs(np.abs(mfeat.numpy().astype(np.float64)).sum() - s["mesh_static_checksum"]) < 1e-3
     assert abs(np.abs(efeat.numpy().astype(np.float64)).sum() - s["edge_feat_checksum"]) < 1e-2
+
+
+@pytest.mark.parametrize("kind,coef", [("kronecker", (0, 0, 1)), ("cartesian", (1, 1, 0)), ("strong", (1, 1, 1))])
+def test_product_graph_equals_dense_kronecker_formula(kind, coef):
+    """create_product_graph (built sparsely) == the reference's dense construction
+    s01 kron(I_T, A) + s10 kron(A_time, I_N) + s11 kron(A_time, A) -> dense_to_sparse
+    (src/models.py:707-774; dense_to_sparse of a 2-D matrix = its non-zero entries in row-major order)."""
+    from sklearn.neighbors import kneighbors_graph
+
+    from graphcast_lite_amd.create_graphs import create_product_graph
+
+    lats, lons, T, k = np.linspace(-60, 60, 5), np.linspace(0, 300, 6), 3, 3
+    pts = np.array([[a, b] for a in lats for b in lons])
+    A = kneighbors_graph(pts, n_neighbors=k, mode="connectivity", include_self=False).toarray()
+    N = pts.shape[0]
+    Tm = np.zeros((T, T))
+    for i in range(T - 1):
+        Tm[i, i + 1] = 1
+    s01, s10, s11 = coef
+    dense = s01 * np.kron(np.eye(T), A) + s10 * np.kron(Tm, np.eye(N)) + s11 * np.kron(Tm, A)
+    want = torch.tensor(dense).nonzero().t()
+    got = create_product_graph(lats, lons, T, k, kind)
+    assert got.dtype == torch.int64 and torch.equal(got, want)

@@ -36,7 +36,8 @@ def make_pair(name, levels, nlat=32, nlon=64, seed=42):
         cfg.pipeline, cfg.data, num_grid_nodes=m._num_grid_nodes, num_mesh_nodes=m._num_mesh_nodes,
         encoding_graph=m.encoding_graph.cpu(), processing_graph=m.processing_graph.cpu(),
         decoding_graph=m.decoding_graph.cpu(), init_grid_features=m.init_grid_features.cpu(),
-        init_mesh_features=m.init_mesh_features.cpu(), processing_edge_features=m._processing_edge_features.cpu())
+        init_mesh_features=m.init_mesh_features.cpu(), processing_edge_features=m._processing_edge_features.cpu(),
+        product_graph=m.product_graph.cpu() if m.use_product_graph else None)
     missing = o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()}, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     return cfg, m, o
@@ -56,7 +57,8 @@ def data(cfg, G, B, seed=1234):
                                            ("region_krsk_cds_19f", [1, 2], 2), ("region_krsk_cds_19f", [2, 3], 1),
                                            ("wb2_512x256_19f_ar_v2", [1, 2], 1),
                                            ("wb2_64x32_15f", [1, 2], 2), ("wb2_64x32_15f", [4, 6], 1),
-                                           ("demo_low", [3], 3)])
+                                           ("demo_low", [3], 3), ("product_graph", [1, 2], 2),
+                                           ("product_graph", [1, 2], 1)])
 def test_forward_backward_parity(name, levels, B):
     from graphcast_lite_amd.train import batch_loss, get_lat_weights
 
