@@ -7,7 +7,6 @@ Adam-state buffer, gradients accumulated in place by the backward kernels, ONE R
 the flat gradient bucket per optimiser step, one fused Adam launch.
 """
 import os
-from typing import List, Optional
 
 import torch
 import torch.distributed as dist
