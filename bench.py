@@ -281,7 +281,8 @@ def main():
                        "parallelism": f"dp{args.gpus}", "final_loss": final_loss,
                        "launch_mode": ("hipGraph replay" + (" (fwd+bwd; all-reduce + Adam eager)" if step.split_finish else "")
                                        if replayed else "eager"),
-                       "settle_steps_before_warmup": settle},
+                       "settle_steps_before_warmup": settle,
+                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
             "roofline": roof,
         }
         if roof is not None:
