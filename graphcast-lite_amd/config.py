@@ -35,43 +35,49 @@ class ProductGraphType(str, Enum):
 
 
 class GraphBuildingConfig(BaseModel):
+    """How the three graphs are built (mesh refinement levels, grid->mesh radius / k, mesh->grid rule)."""
     grid2mesh_edge_creation: Grid2MeshEdgeCreation
-    grid2mesh_radius_query: Optional[float] = None
     grid2mesh_k: Optional[int] = None
-    mesh_levels: List[int]
+    grid2mesh_radius_query: Optional[float] = None
     mesh2grid_edge_creation: Mesh2GridEdgeCreation
+    mesh_levels: List[int]
 
 
 class MLPBlock(BaseModel):
+    """Per-node MLP in front of a graph layer."""
+    layer_norm_mode: Optional[str] = None
     mlp_hidden_dims: Optional[List[int]] = None
     output_dim: int
     use_layer_norm: bool
-    layer_norm_mode: Optional[str] = None
 
 
 class GATProps(BaseModel):
+    """Attention heads and the (unused) sparsity schedule."""
     num_heads: int
     sparsity_thresholds: List[float]
 
 
 class GraphBlock(BaseModel):
-    layer_type: GraphLayerType
+    """One graph layer stack: type, widths, normalisation, activation, InteractionNet options."""
+    activation: Optional[str] = "prelu"
+    edge_feature_dim: Optional[int] = None
     gat_props: Optional[GATProps] = None
     hidden_dims: Optional[List[int]] = None
+    layer_norm_mode: Optional[str] = None
+    layer_type: GraphLayerType
+    num_message_passing_steps: Optional[int] = None
     output_dim: Optional[int] = None
     use_layer_norm: Optional[bool] = None
-    layer_norm_mode: Optional[str] = None
-    activation: Optional[str] = "prelu"
-    num_message_passing_steps: Optional[int] = None
-    edge_feature_dim: Optional[int] = None
 
 
 class ModelConfig(BaseModel):
-    mlp: Optional[MLPBlock] = None
+    """Optional MLP followed by a graph layer."""
     gcn: GraphBlock
+    mlp: Optional[MLPBlock] = None
 
 
 class ProductGraphConfig(BaseModel):
+    """Time x space pre-encoder."""
     model: ModelConfig
     num_k: int
     self_loop: bool
@@ -79,13 +85,15 @@ class ProductGraphConfig(BaseModel):
 
 
 class PipelineConfig(BaseModel):
-    product_graph: Optional[ProductGraphConfig] = None
+    """Encoder / processor / decoder (+ optional product-graph stage)."""
+    decoder: ModelConfig
     encoder: ModelConfig
     processor: ModelConfig
-    decoder: ModelConfig
+    product_graph: Optional[ProductGraphConfig] = None
 
 
 class DataConfig(BaseModel):
+    """Which slice of the dataset the model sees."""
     # the reference restricts dataset_name to an enum of its own dataset directories
     # (`src/config.py:50-65`); the hot path never reads it, so any string is accepted here.
     dataset_name: str
@@ -96,24 +104,25 @@ class DataConfig(BaseModel):
 
 
 class ExperimentConfig(BaseModel):
+    """Top level of an experiments/*/config.json."""
     batch_size: int = 1
-    learning_rate: float = 1e-5
-    early_stopping_patience: int = 10
-    early_stopping_delta: float = 1e-4
-    num_epochs: int = 100
-    random_seed: Optional[int] = 42
-    graph: GraphBuildingConfig
-    pipeline: PipelineConfig
+    boundary_mask_width: int = 0
     data: DataConfig
+    data_dir: Optional[str] = None
+    early_stopping_delta: float = 1e-4
+    early_stopping_patience: int = 10
+    finetune_processor_lr_factor: float = 0.1
+    forcing_channels: List[int] = []
+    freeze_processor_epochs: int = 0
+    graph: GraphBuildingConfig
+    learning_rate: float = 1e-5
+    max_ar_steps: int = 1
+    num_epochs: int = 100
+    pipeline: PipelineConfig
+    random_seed: Optional[int] = 42
+    roi_only_loss: bool = False
+    static_channels: List[int] = []
+    use_latitude_weighting: bool = True
+    use_residual: bool = True
     wandb_log: bool = True
     wandb_name: Optional[str] = None
-    use_latitude_weighting: bool = True
-    max_ar_steps: int = 1
-    data_dir: Optional[str] = None
-    static_channels: List[int] = []
-    forcing_channels: List[int] = []
-    roi_only_loss: bool = False
-    boundary_mask_width: int = 0
-    freeze_processor_epochs: int = 0
-    finetune_processor_lr_factor: float = 0.1
-    use_residual: bool = True
