@@ -352,7 +352,8 @@ def _act_ref(x, act, a):
 
 
 @pytest.mark.parametrize("rows,Fin,Fout", [(1000, 256, 256), (333, 512, 256), (700, 256, 512), (129, 260, 132),
-                                           (5000, 128, 64), (64, 768, 256), (1, 256, 256)])
+                                           (5000, 128, 64), (64, 768, 256), (1, 256, 256),
+                                           (4500, 260, 132)])  # >= 4096 rows: dX runs on workspace-transposed weights
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_dense_fwd_bwd_wide(hip, rows, Fin, Fout, act):
     """gcl_dense_*: wide layers (tiled contraction), SiLU / PReLU on load, weight column blocks (ldw > Fin),
