@@ -102,10 +102,11 @@ class MLPFn(torch.autograd.Function):
             if k > 0:
                 # one fused launch: dz_{k-1}, dW_k, db_k, d(slope_{k-1})
                 dz = hip.linear_bwd_all(dz, W, inp, slope, G.dst[3 * k - 1], dW, db, None, G.acc[wi])
+            elif ctx.needs_input_grad[0]:
+                # first layer with a differentiable input: dx, dW and db from one read of dz
+                dx = hip.linear_bwd_all(dz, W, inp, None, None, dW, db, None, G.acc[wi], act=hip.ACT_NONE)
             else:
                 hip.linear_bwd_dw(dz, inp, None, dW, db, G.acc[wi])
-                if ctx.needs_input_grad[0]:
-                    dx = hip.linear_bwd_dx(dz, W, None, None, None)
         if dx is not None:
             dx = dx.view(dy.shape[:-1] + (dx.shape[-1],))
         return (dx, None, None, None) + G.out()
@@ -222,10 +223,11 @@ class GCNStackFn(torch.autograd.Function):
                 # conv k-1 (= column sums of dp_{k-1})
                 dp = hip.linear_bwd_all(dh2, W, inp, slope_t, dsl, dW, None, G.dst[2 * k - 1], G.acc[wi],
                                         act=akind).view(B, n, -1)
+            elif ctx.needs_input_grad[0]:
+                dx = hip.linear_bwd_all(dh2, W, inp, None, None, dW, None, None, G.acc[wi],
+                                        act=hip.ACT_NONE).view(B, n, -1)
             else:
                 hip.linear_bwd_dw(dh2, inp, None, dW, None, G.acc[wi])
-                if ctx.needs_input_grad[0]:
-                    dx = hip.linear_bwd_dx(dh2, W, None, None, None).view(B, n, -1)
             if padded:
                 G.acc[wi] = acc_real
                 dW_real.add_(dW[:pad[1]]) if acc_real else dW_real.copy_(dW[:pad[1]])
