@@ -114,6 +114,7 @@ __device__ __forceinline__ void gn_sum_parts(const double* fin, int b, double& s
   s1 = fin[2 * b + 1];
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void gn_fwd_apply_kernel(const float* __restrict__ X, int64_t ldx, int64_t bsx,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps,
@@ -132,6 +133,23 @@ __global__ __launch_bounds__(256) void gn_fwd_apply_kernel(const float* __restri
   if (blockIdx.x == 0 && threadIdx.x == 0 && stats) {
     stats[2 * b] = mean;
     stats[2 * b + 1] = rinv;
+  }
+  if (VEC) {  // 16-byte rows: one float4 of x, gamma, beta per step
+    const int F4 = F >> 2;
+    const int64_t total4 = (int64_t)n * F4;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
+      const int r = (int)(idx / F4), c = (int)(idx % F4) * 4;
+      const float4 x = *reinterpret_cast<const float4*>(X + (int64_t)b * bsx + (int64_t)r * ldx + c);
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+      const float4 be = *reinterpret_cast<const float4*>(beta + c);
+      float4 y;
+      y.x = (x.x - mean) * rinv * g.x + be.x;
+      y.y = (x.y - mean) * rinv * g.y + be.y;
+      y.z = (x.z - mean) * rinv * g.z + be.z;
+      y.w = (x.w - mean) * rinv * g.w + be.w;
+      *reinterpret_cast<float4*>(Y + (int64_t)b * bsy + (int64_t)r * ldy + c) = y;
+    }
+    return;
   }
   const int64_t total = (int64_t)n * F;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
@@ -213,9 +231,17 @@ extern "C" int gcl_graphnorm_fwd(const float* x, int64_t ldx, int64_t bsx, const
     hipLaunchKernelGGL((gn_partial_kernel<0, false>), dim3(nch, B), dim3(256), 0, st, x, ldx, bsx, nullptr, 0, 0,
                        nullptr, nullptr, part, n, F);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, part, fin, nch);
-  const unsigned nb = (unsigned)std::min<int64_t>(gcl::cdiv((int64_t)n * F, 256), 1024);
-  hipLaunchKernelGGL(gn_fwd_apply_kernel, dim3(nb, B), dim3(256), 0, st, x, ldx, bsx, gamma, beta, eps, fin, y, ldy,
-                     bsy, stats, n, F);
+  const bool vec_all = vec && (ldy % 4 == 0) && (bsy % 4 == 0) && gcl::aligned16(y) && gcl::aligned16(gamma) &&
+                       gcl::aligned16(beta);
+  if (vec_all) {
+    const unsigned nb = (unsigned)std::min<int64_t>(gcl::cdiv((int64_t)n * (F / 4), 256), 4096);
+    hipLaunchKernelGGL(gn_fwd_apply_kernel<true>, dim3(nb, B), dim3(256), 0, st, x, ldx, bsx, gamma, beta, eps, fin, y,
+                       ldy, bsy, stats, n, F);
+  } else {
+    const unsigned nb = (unsigned)std::min<int64_t>(gcl::cdiv((int64_t)n * F, 256), 1024);
+    hipLaunchKernelGGL(gn_fwd_apply_kernel<false>, dim3(nb, B), dim3(256), 0, st, x, ldx, bsx, gamma, beta, eps, fin, y,
+                       ldy, bsy, stats, n, F);
+  }
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
