@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256) void gn_fwd_apply_kernel(const float* __restri
 }
 
 // dx and per-block column partials of (dy*xhat | dy): cpart[block][2][F]
+template <bool VEC>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ dY, int64_t lddy, int64_t bsdy,
                                                            const float* __restrict__ X, int64_t ldx, int64_t bsx,
                                                            const float* __restrict__ gamma,
@@ -178,6 +179,37 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   const float gmean = (float)(s0 / N);
   const float k2 = sd > 0.0 ? (float)(s1 / (N * sd * d * d)) : 0.f;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+  if (VEC) {
+    // thread t owns the float4 column t % (F/4) of rows r0 + t / (F/4), stepping 256 / (F/4) rows
+    // (F/4 divides 256): four fixed columns per thread, 16-byte accesses
+    const int F4 = F >> 2;
+    const int c = (threadIdx.x % F4) * 4, rsub = threadIdx.x / F4, rstep = 256 / F4;
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+    float4 pg = make_float4(0.f, 0.f, 0.f, 0.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0 + rsub; r < r1; r += rstep) {
+      const float4 x = *reinterpret_cast<const float4*>(X + (int64_t)b * bsx + (int64_t)r * ldx + c);
+      const float4 dy = *reinterpret_cast<const float4*>(dY + (int64_t)b * bsdy + (int64_t)r * lddy + c);
+      const float4 xc = make_float4(x.x - mean, x.y - mean, x.z - mean, x.w - mean);
+      float4 o;
+      o.x = (dy.x * gm.x - gmean) * rinv - xc.x * k2;
+      o.y = (dy.y * gm.y - gmean) * rinv - xc.y * k2;
+      o.z = (dy.z * gm.z - gmean) * rinv - xc.z * k2;
+      o.w = (dy.w * gm.w - gmean) * rinv - xc.w * k2;
+      *reinterpret_cast<float4*>(dX + (int64_t)b * bsdx + (int64_t)r * lddx + c) = o;
+      pg.x += dy.x * xc.x * rinv; pg.y += dy.y * xc.y * rinv; pg.z += dy.z * xc.z * rinv; pg.w += dy.w * xc.w * rinv;
+      pb.x += dy.x; pb.y += dy.y; pb.z += dy.z; pb.w += dy.w;
+    }
+    *reinterpret_cast<float4*>(cs + rsub * 2 * F + c) = pg;
+    *reinterpret_cast<float4*>(cs + rsub * 2 * F + F + c) = pb;
+    __syncthreads();
+    float* out = cpart + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * F;
+    for (int q = threadIdx.x; q < 2 * F; q += 256) {
+      float t = 0.f;
+      for (int k = 0; k < rstep; ++k) t += cs[k * 2 * F + q];
+      out[q] = t;
+    }
+    return;
+  }
   // thread t owns column t % F of rows r0 + t / F, stepping 256 / F rows (F <= 256): its column is fixed
   const int c = threadIdx.x % F, rsub = threadIdx.x / F, rstep = 256 / F;
   float pg = 0.f, pb = 0.f;
@@ -269,8 +301,14 @@ extern "C" int gcl_graphnorm_bwd(const float* dy, int64_t lddy, int64_t bsdy, co
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, part, fin, nch);
   const int rows_per_block = 256;
   const unsigned nblk = (unsigned)gcl::cdiv(n, rows_per_block);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nblk, B), dim3(256), 2 * (size_t)F * (256 / F) * sizeof(float), st, dy, lddy, bsdy, x,
-                     ldx, bsx, gamma, stats, eps, fin, dx, lddx, bsdx, cpart, n, F, rows_per_block);
+  const int F4 = F / 4;
+  const bool vec_apply = vec && F4 >= 1 && (256 % F4 == 0) && (lddx % 4 == 0) && (bsdx % 4 == 0) && gcl::aligned16(dx);
+  if (vec_apply)
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(nblk, B), dim3(256), 2 * (size_t)F * (256 / F4) * sizeof(float), st,
+                       dy, lddy, bsdy, x, ldx, bsx, gamma, stats, eps, fin, dx, lddx, bsdx, cpart, n, F, rows_per_block);
+  else
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(nblk, B), dim3(256), 2 * (size_t)F * (256 / F) * sizeof(float), st,
+                       dy, lddy, bsdy, x, ldx, bsx, gamma, stats, eps, fin, dx, lddx, bsdx, cpart, n, F, rows_per_block);
   GCL_CHECK_LAUNCH();
   const int nparts = (int)(nblk * B);
   int rc = gcl::launch_reduce_parts(cpart, nparts, 2 * F, 2 * F, dgamma, F, 1, F, accumulate, st);
