@@ -139,10 +139,8 @@ class GCNStackFn(torch.autograd.Function):
                 # its whole backward onto scalar memory accesses.  Run it ldh wide instead, with zero
                 # weight rows / bias entries for the extra columns (they stay exactly 0), and return
                 # the first Fout columns as a view.
-                Wp = W.new_zeros(ldh, W.shape[1])
-                Wp[:Fout].copy_(W)
-                bp = b.new_zeros(ldh)
-                bp[:Fout].copy_(b)
+                Wp = torch.nn.functional.pad(W, (0, 0, 0, ldh - Fout))
+                bp = torch.nn.functional.pad(b, (0, ldh - Fout))
                 if hip.gcn_layer_fusable(graph, cur, W.shape[1], ldh):
                     p = hip.gcn_layer_fwd(graph, cur, akind if k > 0 else hip.ACT_NONE, slope_t if k > 0 else None, Wp, bp)
                 else:
@@ -197,9 +195,7 @@ class GCNStackFn(torch.autograd.Function):
         pad = ctx.pad_last
         if pad is not None:  # widen the incoming gradient to the padded width (extra columns 0)
             Fp, Fo, Wp = pad
-            dpp = dy3.new_zeros(B, n, Fp)
-            dpp[..., :Fo].copy_(dy3)
-            dp = dpp
+            dp = torch.nn.functional.pad(dy3, (0, Fp - Fo))  # one pass: copy + zero columns
         bi_last = 2 * L - 1
         if G.dst[bi_last] is not None:  # bias of the last conv: its dp comes from outside this stack
             if pad is None:
