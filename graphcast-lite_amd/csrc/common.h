@@ -61,6 +61,10 @@ __device__ __forceinline__ float dsilu_f(float z) {
 // out[i*ldo + j] (+)= sum_p part[p*pstride + i*pld + j], i < R, j < C (parallel over partials, fixed order)
 int launch_reduce_parts(const float* part, int nparts, int64_t pstride, int pld, float* out, int ldo, int R, int C,
                         int accumulate, hipStream_t st);
+// two vectors of one partial record in ONE launch: out0[j] (+)= sum_p part[p*pstride + j],
+// out1[j] (+)= sum_p part[p*pstride + off1 + j], j < C (each vector padded to pld entries in the record)
+int launch_reduce_parts2(const float* part, int nparts, int64_t pstride, int pld, int off1, float* out0, float* out1,
+                         int C, int accumulate, hipStream_t st);
 
 }  // namespace gcl
 

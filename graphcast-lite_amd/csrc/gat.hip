@@ -574,9 +574,7 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
 #undef CALL
   GCL_CHECK_LAUNCH();
   const int HC = H * C;
-  rc = gcl::launch_reduce_parts(part, (int)nbd, 2 * HC, 2 * HC, d_att_src, HC, 1, HC, accumulate, st);
-  if (rc) return rc;
-  rc = gcl::launch_reduce_parts(part + HC, (int)nbd, 2 * HC, 2 * HC, d_att_dst, HC, 1, HC, accumulate, st);
+  rc = gcl::launch_reduce_parts2(part, (int)nbd, 2 * HC, HC, HC, d_att_src, d_att_dst, HC, accumulate, st);
   if (rc) return rc;
   if (d_bias) {
     // dy rows are contiguous across the batch (checked above): one flat column sum

@@ -311,7 +311,5 @@ extern "C" int gcl_graphnorm_bwd(const float* dy, int64_t lddy, int64_t bsdy, co
                        dy, lddy, bsdy, x, ldx, bsx, gamma, stats, eps, fin, dx, lddx, bsdx, cpart, n, F, rows_per_block);
   GCL_CHECK_LAUNCH();
   const int nparts = (int)(nblk * B);
-  int rc = gcl::launch_reduce_parts(cpart, nparts, 2 * F, 2 * F, dgamma, F, 1, F, accumulate, st);
-  if (rc) return rc;
-  return gcl::launch_reduce_parts(cpart + F, nparts, 2 * F, 2 * F, dbeta, F, 1, F, accumulate, st);
+  return gcl::launch_reduce_parts2(cpart, nparts, 2 * F, F, F, dgamma, dbeta, F, accumulate, st);
 }

@@ -1053,6 +1053,15 @@ int launch_reduce_parts(const float* part, int nparts, int64_t pstride, int pld,
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
+int launch_reduce_parts2(const float* part, int nparts, int64_t pstride, int pld, int off1, float* out0, float* out1,
+                         int C, int accumulate, hipStream_t st) {
+  RedSeg s0{out0, 0, pld, pld, C, C};
+  RedSeg s1{out1, off1, pld, pld, C, C};
+  RedSeg none{nullptr, 0, 0, 1, 0, 0};
+  launch_reduce_multi(part, nparts, pstride, s0, s1, none, accumulate, st);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
 }  // namespace gcl
 
 namespace {

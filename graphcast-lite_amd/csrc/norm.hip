@@ -227,9 +227,7 @@ extern "C" int gcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
   GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
   GCL_CHECK_LAUNCH();
-  int rc = gcl::launch_reduce_parts(part, (int)nb, 2 * FP, 2 * FP, dgamma, F, 1, F, accumulate, st);
-  if (rc) return rc;
-  return gcl::launch_reduce_parts(part + FP, (int)nb, 2 * FP, 2 * FP, dbeta, F, 1, F, accumulate, st);
+  return gcl::launch_reduce_parts2(part, (int)nb, 2 * FP, FP, FP, dgamma, dbeta, F, accumulate, st);
 }
 
 extern "C" size_t gcl_colsum_ws_bytes(int64_t rows, int32_t F) {
