@@ -931,7 +931,17 @@ struct RedSeg {
 };
 __global__ __launch_bounds__(256) void reduce_multi_kernel(const float* __restrict__ part, int32_t nparts,
                                                            int64_t pstride, RedSeg s0, RedSeg s1, RedSeg s2,
-                                                           int32_t accumulate) {
+                                                           int32_t accumulate, const double* __restrict__ spart, int32_t ns,
+                                                           float* __restrict__ sout) {
+  if (spart && blockIdx.x == gridDim.x - 1) {  // one extra block: the scalar (PReLU slope) partials, fixed order
+    if (threadIdx.x < 64) {
+      double t = 0.0;
+      for (int p = threadIdx.x; p < ns; p += 64) t += spart[p];
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+      if (threadIdx.x == 0) *sout += (float)t;
+    }
+    return;
+  }
   __shared__ float red[16][17];
   const int e16 = threadIdx.x & 15, g = threadIdx.x >> 4;
   int idx = blockIdx.x * 16 + e16;
@@ -967,7 +977,17 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const float* __restri
 // fixed-order combine through LDS.  Needs pstride, every poff and every count to be multiples of 4.
 __global__ __launch_bounds__(256) void reduce_multi4_kernel(const float* __restrict__ part, int32_t nparts,
                                                             int64_t pstride, RedSeg s0, RedSeg s1, RedSeg s2,
-                                                            int32_t accumulate) {
+                                                            int32_t accumulate, const double* __restrict__ spart, int32_t ns,
+                                                            float* __restrict__ sout) {
+  if (spart && blockIdx.x == gridDim.x - 1) {  // one extra block: the scalar (PReLU slope) partials, fixed order
+    if (threadIdx.x < 64) {
+      double t = 0.0;
+      for (int p = threadIdx.x; p < ns; p += 64) t += spart[p];
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+      if (threadIdx.x == 0) *sout += (float)t;
+    }
+    return;
+  }
   __shared__ float red[32][33];
   const int l8 = threadIdx.x & 7, g = threadIdx.x >> 3;
   int idx = blockIdx.x * 32 + l8 * 4;  // first of this lane's 4 elements, in the concatenated segments
@@ -1029,16 +1049,19 @@ __global__ __launch_bounds__(256) void reduce_multi4_kernel(const float* __restr
 
 // picks the 16-byte variant when the record layout allows it
 inline void launch_reduce_multi(const float* part, int nparts, int64_t pstride, const RedSeg& s0, const RedSeg& s1,
-                                const RedSeg& s2, int accumulate, hipStream_t st) {
+                                const RedSeg& s2, int accumulate, hipStream_t st, const double* spart = nullptr,
+                                int ns = 0, float* sout = nullptr) {
   const int total = s0.count + s1.count + s2.count;
   const bool vec = (pstride % 4 == 0) && ((s0.poff | s1.poff | s2.poff | s0.count | s1.count | s2.count) % 4 == 0) &&
                    gcl::aligned16(part) && nparts >= 64;
+  const unsigned extra = (spart && sout && ns > 0) ? 1u : 0u;  // one more block for the scalar partials
+  const double* sp = extra ? spart : nullptr;
   if (vec)
-    hipLaunchKernelGGL(reduce_multi4_kernel, dim3((unsigned)gcl::cdiv(total, 32)), dim3(256), 0, st, part, nparts, pstride,
-                       s0, s1, s2, accumulate);
+    hipLaunchKernelGGL(reduce_multi4_kernel, dim3((unsigned)gcl::cdiv(total, 32) + extra), dim3(256), 0, st, part, nparts,
+                       pstride, s0, s1, s2, accumulate, sp, ns, sout);
   else
-    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)gcl::cdiv(total, 16)), dim3(256), 0, st, part, nparts, pstride,
-                       s0, s1, s2, accumulate);
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)gcl::cdiv(total, 16) + extra), dim3(256), 0, st, part, nparts,
+                       pstride, s0, s1, s2, accumulate, sp, ns, sout);
 }
 
 }  // namespace
@@ -1503,11 +1526,9 @@ extern "C" int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W,
     RedSeg s0{dW, 0, Fout * FiP, FiP, Fin, Fin};
     RedSeg s1{db, FoP * FiP, db ? Fout : 0, FoP, Fout, 0};
     RedSeg s2{colsum_dx, FoP * FiP + FoP, colsum_dx ? Fin : 0, FiP, Fin, 0};
-    launch_reduce_multi(part_dw, nblk, rec, s0, s1, s2, accumulate, st);
-    GCL_CHECK_LAUNCH();
-  }
-  if (want_slope) {
-    hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(64), 0, st, part_sl, nblk, d_in_slope);
+    // + the slope partials (one extra block of the same launch)
+    launch_reduce_multi(part_dw, nblk, rec, s0, s1, s2, accumulate, st, want_slope ? part_sl : nullptr, nblk,
+                        d_in_slope);
     GCL_CHECK_LAUNCH();
   }
   return GCL_OK;
