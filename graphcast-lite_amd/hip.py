@@ -463,7 +463,8 @@ def wmse_fwd_bwd(delta3, x_last3, y3, node_w, chan_w, inv_wsum, grad_scale, want
     """delta3 [B,G,C] contiguous; x_last3 / y3 may be strided views (unit channel stride)."""
     B, G, Cc = delta3.shape
     dev = delta3.device
-    delta3 = delta3.contiguous()
+    if delta3.stride(2) != 1:
+        delta3 = delta3.contiguous()  # (a row-strided view - e.g. the grid rows of a padded output - is read in place)
     dd = torch.empty(B, G, Cc, dtype=torch.float32, device=dev) if want_grad else None
     st = torch.empty(B, G, Cc, dtype=torch.float32, device=dev) if want_state else None
     loss = torch.empty((), dtype=torch.float32, device=dev)
@@ -471,7 +472,7 @@ def wmse_fwd_bwd(delta3, x_last3, y3, node_w, chan_w, inv_wsum, grad_scale, want
     ws = workspace(nb, dev)
     xl = x_last3
     _check(lib().gcl_wmse_fwd_bwd(
-        _p(delta3), Cc, G * Cc, _p(xl), xl.stride(1) if xl is not None else 0, xl.stride(0) if xl is not None else 0,
+        _p(delta3), delta3.stride(1), delta3.stride(0), _p(xl), xl.stride(1) if xl is not None else 0, xl.stride(0) if xl is not None else 0,
         _p(y3), y3.stride(1), y3.stride(0), _p(node_w), _p(chan_w), float(inv_wsum), float(grad_scale), _p(dd), _p(st),
         _p(loss), B, G, Cc, ws.data_ptr(), ws.numel(), _stream()))
     return loss, dd, st
