@@ -105,6 +105,101 @@ def cpu_baseline(cfg, model, grid, budget_s=12.0, max_steps=2000):
             "value_1thread": n1 / dt1}
 
 
+WORKLOADS = {  # --config -> the BASELINE.json entry it measures (None: not a BASELINE.json config)
+    "baseline": "BASELINE.json configs[1]: Baseline GCN processor, wb2_64x32 33-feat, batch=64 samples",
+    "attention": "BASELINE.json configs[2]: Attention (GATConv processor, H=1) wb2_64x32, batch=64",
+    "wb2_512x256_19f_ar": "BASELINE.json configs[3]: Baseline GCN, wb2_512x256 19-feat, batch=8 per GPU",
+    "wb2_512x256_sparse_gat": "BASELINE.json configs[4]: SparseGATConv processor with edge pruning, wb2_512x256",
+}
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` WITHOUT a launcher (WORLD_SIZE unset): start N fresh rank processes,
+    one per GPU, BEFORE this process makes any GPU call (it never makes one), with the torchrun
+    environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  Rank 0 prints the JSON
+    line on the inherited stdout.  Returns non-zero - and prints no benchmark line of its own - when the
+    ranks cannot be started or any of them fails: an N-GPU number is only ever produced by N ranks."""
+    import subprocess
+
+    one_dev = os.environ.get("GCL_BENCH_ONE_DEVICE", "0") == "1"
+    selftest = os.environ.get("GCL_BENCH_SELFTEST", "0") == "1"
+    if not (one_dev or selftest):
+        have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+        if have < n:
+            print(f"bench.py: --gpus {n} requested but this node exposes {have} GPU(s); refusing to report an "
+                  f"{n}-GPU number from fewer devices", file=sys.stderr, flush=True)
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GCL_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    try:
+        deadline = time.time() + float(os.environ.get("GCL_BENCH_RANK_TIMEOUT", "1500"))
+        pending = list(procs)
+        while pending:
+            for pr in list(pending):
+                code = pr.poll()
+                if code is not None:
+                    pending.remove(pr)
+                    if code != 0 and rc == 0:
+                        rc = code if code > 0 else 1
+            if rc != 0 or time.time() > deadline:
+                rc = rc or 3
+                break
+            time.sleep(0.05)
+    finally:
+        for pr in procs:  # exactly the processes started above, by handle
+            if pr.poll() is None:
+                pr.kill()
+        for pr in procs:
+            pr.wait()
+    if rc != 0:
+        print(f"bench.py: a rank process failed (rc {rc}); no benchmark line", file=sys.stderr, flush=True)
+    return rc
+
+
+def init_dist(args):
+    """(world, rank, local) from the launcher's environment; the process group is RCCL ("nccl") unless the
+    one-GPU rehearsal knob GCL_DIST_BACKEND=gloo is set.  `--gpus` must equal the real world size."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("GCL_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        world = dist.get_world_size()  # what the process group really has
+    return world, rank, local
+
+
+def selftest(args) -> None:
+    """GCL_BENCH_SELFTEST=1 (CPU, gloo): exercises only the launcher + rendezvous + reduction plumbing of
+    this file and prints a line whose `n_gpus` comes from dist.get_world_size()."""
+    os.environ.setdefault("GCL_DIST_BACKEND", "gloo")
+    world, rank, _ = init_dist(args)
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "rank_sum": float(t.item()),
+                          "spawned": os.environ.get("GCL_BENCH_SPAWNED", "0") == "1"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,18 +215,22 @@ def main():
                          "hipGraph (then the roofline events are recorded inside the timed region itself)")
     ap.add_argument("--graph", action="store_true", help="(default) kept for older command lines")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # rehearsal knobs for a one-GPU box (never used by the driver): GCL_DIST_BACKEND=gloo lets several
-        # ranks share device 0 (RCCL refuses two ranks on one device), GCL_BENCH_ONE_DEVICE=1 maps them there
-        dist.init_process_group(os.environ.get("GCL_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become the launcher (one child process per GPU; this process stays off the GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("GCL_BENCH_SELFTEST", "0") == "1":
+        return selftest(args)
+
+    # rehearsal knobs for a one-GPU box (never used by the driver): GCL_DIST_BACKEND=gloo lets several
+    # ranks share device 0 (RCCL refuses two ranks on one device), GCL_BENCH_ONE_DEVICE=1 maps them there
+    world, rank, local = init_dist(args)
     if os.environ.get("GCL_BENCH_ONE_DEVICE", "0") == "1":
         local = 0
+    elif local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -145,7 +244,7 @@ def main():
     X, y = synthetic_batch(cfg, G, B, seed=1234 + rank)  # every rank its own samples
     X, y = X.to(dev), y.to(dev)                           # resident in HBM before the timed region
     step = TrainStep(model, lr=1e-3, lat_weights=get_lat_weights(grid[0], grid[1], dev), world_size=world,
-                     use_graph=not args.eager)
+                     use_graph=False if args.eager else None)
 
     # Untimed settle phase before the W official warm-up steps: a freshly acquired box can run the
     # first seconds several times slower (clock ramp / code-object and allocator warm-up).  Step until
@@ -178,7 +277,7 @@ def main():
                                  "Fin": cfg.pipeline.processor.gcn.output_dim,
                                  "Fout": cfg.pipeline.processor.gcn.output_dim, "events": []}
 
-    replayed = bool(step.use_graph and step._graph is not None)
+    replayed = step.graph_active
     if not replayed:
         arm_profile()  # eager timed region: the events sit inside it
     if world > 1:
@@ -271,16 +370,17 @@ def main():
     if rank == 0:
         out = {
             "metric": "training samples/sec (6h windows) + achieved HBM GB/s on mesh GCNConv",
-            "value": args.gpus * B * args.steps / dt, "unit": "samples/s", "n_gpus": args.gpus,
+            "value": world * B * args.steps / dt, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.config} (BASELINE.json configs[1] family): grid {grid[1]}x{grid[0]}, "
-                                   f"G={G}, mesh M={M}, {cfg.data.num_features_used} feat, obs 2, AR 1, "
-                                   f"fwd+loss+bwd+Adam", "batch_per_gpu": B, "global_batch": B * args.gpus,
-                       "parallelism": f"dp{args.gpus}", "final_loss": final_loss,
-                       "launch_mode": ("hipGraph replay" + (" (fwd+bwd; all-reduce + Adam eager)" if step.split_finish else "")
-                                       if replayed else "eager"),
+            "config": {"workload": f"{WORKLOADS.get(args.config) or args.config + ' (not a BASELINE.json config; SURVEY.md 8f)'}"
+                                   f" - grid {grid[1]}x{grid[0]}, G={G}, mesh M={M}, {cfg.data.num_features_used} feat, "
+                                   f"obs {cfg.data.obs_window_used}, AR 1, fwd+loss+bwd+Adam",
+                       "experiment": args.config, "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": f"dp{world}", "world_size": world,
+                       "dist_backend": (dist.get_backend() if world > 1 else None), "final_loss": final_loss,
+                       "launch_mode": step.launch_mode,
                        "settle_steps_before_warmup": settle,
                        "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
             "roofline": roof,
@@ -288,7 +388,7 @@ def main():
         if roof is not None:
             roof["measured_on"] = (f"{roof_steps} eager steps right after the timed region ({roof_ms:.2f} ms/step eager)"
                                    if roof_pass else "the timed steps themselves")
-        if args.gpus == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model, grid)
         print(json.dumps(out), flush=True)
     if world > 1:

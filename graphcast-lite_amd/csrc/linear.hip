@@ -86,7 +86,10 @@ __global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel
                                                           int64_t ldy, int64_t rows, int32_t K, int32_t N,
                                                           const float* __restrict__ Z, int64_t ldz,
                                                           const float* __restrict__ z_slope,
-                                                          double* __restrict__ slope_part, int32_t akind) {
+                                                          double* __restrict__ slope_part, int32_t akind,
+                                                          int32_t abl) {
+  // abl: timing-only ablation bits of tools/ablate.sh (0 in the product): 1 = drop the stores (empty
+  // window), 2 = skip the MFMA loop, 4 = loads read the zero page.  Runtime values: codegen is unchanged.
   extern __shared__ __align__(16) float smem[];
   const int KE = (K + 3) & ~3;        // K padded to a multiple of 4 (two MFMA k-steps per 8-B read)
   const int KP = KE + 2;              // even stride with KP/2 odd: conflict-free ds_read_b64 fragments
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel
   const int rsub = (CPR >= 64) ? 0 : lane / CPR;
   const int csub = (CPR >= 64) ? lane : lane % CPR;
   float pre[VEC ? NIT * 4 : NIT];
-  // per-lane constant parts of the staging offsets (bytes); masked columns point out of range
+  const int64_t rows_ld = (abl & 4) ? 0 : rows;
   auto issue = [&](int64_t tile) {  // rows past the end (and tiles past the last) read the zero page
     const int64_t r0 = tile * TM + wave * 32;
 #pragma unroll
@@ -128,12 +131,12 @@ __global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel
       const int64_t row = r0 + (it / IPR) * RPI + rsub;
       const int c = csub + 64 * (it % IPR);
       if (VEC) {
-        const bool ok = (c * 4 < K) && (row < rows);
+        const bool ok = (c * 4 < K) && (row < rows_ld);
         const float4* p = ok ? reinterpret_cast<const float4*>(X + row * ldx + c * 4) : gcl_zero4;
         const float4 v = *p;
         pre[4 * it] = v.x; pre[4 * it + 1] = v.y; pre[4 * it + 2] = v.z; pre[4 * it + 3] = v.w;
       } else {
-        const bool ok = (c < K) && (row < rows);
+        const bool ok = (c < K) && (row < rows_ld);
         const float* p = ok ? X + row * ldx + c : reinterpret_cast<const float*>(gcl_zero4);
         pre[it] = *p;
       }
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel
 
     const int64_t r0 = t * TM;
     const int64_t nr = (rows - r0) < TM ? (rows - r0) : TM;
-    const __amdgpu_buffer_rsrc_t ry = make_rsrc(Y + r0 * ldy, win_bytes(nr, ldy, N));
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(Y + r0 * ldy, (abl & 1) ? 0 : win_bytes(nr, ldy, N));
     const __amdgpu_buffer_rsrc_t rz = make_rsrc(has_z ? Z + r0 * ldz : Y, has_z ? win_bytes(nr, ldz, N) : 0);
 
     f32x16 acc[NS];
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel
     // use the same assignment.  Fragments of pair q+1 are read before the MFMAs of pair q issue.
     const float* ap = Xw + (lane & 31) * KP + 2 * (lane >> 5);
     const float* bp = Wl + (lane & 31) * KP + 2 * (lane >> 5);
-    const int nq = KE >> 2;
+    const int nq = (abl & 2) ? 0 : (KE >> 2);
     float2 a_c = *reinterpret_cast<const float2*>(ap);
     float2 b_c[NS];
 #pragma unroll
@@ -928,10 +931,11 @@ __global__ void reduce_scalar_kernel(const double* __restrict__ part, int32_t np
 struct RedSeg {
   float* out;
   int32_t poff, count, pld, cols, ldo;
+  int32_t acc;  // add into out (1) or overwrite it (0): every destination has its own flag
 };
 __global__ __launch_bounds__(256) void reduce_multi_kernel(const float* __restrict__ part, int32_t nparts,
                                                            int64_t pstride, RedSeg s0, RedSeg s1, RedSeg s2,
-                                                           int32_t accumulate, const double* __restrict__ spart, int32_t ns,
+                                                           const double* __restrict__ spart, int32_t ns,
                                                            float* __restrict__ sout) {
   if (spart && blockIdx.x == gridDim.x - 1) {  // one extra block: the scalar (PReLU slope) partials, fixed order
     if (threadIdx.x < 64) {
@@ -967,7 +971,7 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const float* __restri
     const int i = idx / sg.pld, j = idx - i * sg.pld;
     if (j < sg.cols) {
       float* o = sg.out + (size_t)i * sg.ldo + j;
-      *o = accumulate ? *o + tot : tot;
+      *o = sg.acc ? *o + tot : tot;
     }
   }
 }
@@ -977,7 +981,7 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const float* __restri
 // fixed-order combine through LDS.  Needs pstride, every poff and every count to be multiples of 4.
 __global__ __launch_bounds__(256) void reduce_multi4_kernel(const float* __restrict__ part, int32_t nparts,
                                                             int64_t pstride, RedSeg s0, RedSeg s1, RedSeg s2,
-                                                            int32_t accumulate, const double* __restrict__ spart, int32_t ns,
+                                                            const double* __restrict__ spart, int32_t ns,
                                                             float* __restrict__ sout) {
   if (spart && blockIdx.x == gridDim.x - 1) {  // one extra block: the scalar (PReLU slope) partials, fixed order
     if (threadIdx.x < 64) {
@@ -1041,7 +1045,7 @@ __global__ __launch_bounds__(256) void reduce_multi4_kernel(const float* __restr
       const int i = e / so.pld, j = e - i * so.pld;
       if (j < so.cols) {
         float* o = so.out + (size_t)i * so.ldo + j;
-        *o = accumulate ? *o + tot : tot;
+        *o = so.acc ? *o + tot : tot;
       }
     }
   }
@@ -1049,7 +1053,7 @@ __global__ __launch_bounds__(256) void reduce_multi4_kernel(const float* __restr
 
 // picks the 16-byte variant when the record layout allows it
 inline void launch_reduce_multi(const float* part, int nparts, int64_t pstride, const RedSeg& s0, const RedSeg& s1,
-                                const RedSeg& s2, int accumulate, hipStream_t st, const double* spart = nullptr,
+                                const RedSeg& s2, hipStream_t st, const double* spart = nullptr,
                                 int ns = 0, float* sout = nullptr) {
   const int total = s0.count + s1.count + s2.count;
   const bool vec = (pstride % 4 == 0) && ((s0.poff | s1.poff | s2.poff | s0.count | s1.count | s2.count) % 4 == 0) &&
@@ -1058,10 +1062,10 @@ inline void launch_reduce_multi(const float* part, int nparts, int64_t pstride, 
   const double* sp = extra ? spart : nullptr;
   if (vec)
     hipLaunchKernelGGL(reduce_multi4_kernel, dim3((unsigned)gcl::cdiv(total, 32) + extra), dim3(256), 0, st, part, nparts,
-                       pstride, s0, s1, s2, accumulate, sp, ns, sout);
+                       pstride, s0, s1, s2, sp, ns, sout);
   else
     hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)gcl::cdiv(total, 16) + extra), dim3(256), 0, st, part, nparts,
-                       pstride, s0, s1, s2, accumulate, sp, ns, sout);
+                       pstride, s0, s1, s2, sp, ns, sout);
 }
 
 }  // namespace
@@ -1070,24 +1074,29 @@ namespace gcl {
 int launch_reduce_parts(const float* part, int nparts, int64_t pstride, int pld, float* out, int ldo, int R, int C,
                         int accumulate, hipStream_t st) {
   // one segment of the 16-way reducer: R rows of pld (padded) columns, C of them valid
-  RedSeg s0{out, 0, R * pld, pld, C, ldo};
-  RedSeg none{nullptr, 0, 0, 1, 0, 0};
-  launch_reduce_multi(part, nparts, pstride, s0, none, none, accumulate, st);
+  RedSeg s0{out, 0, R * pld, pld, C, ldo, accumulate};
+  RedSeg none{nullptr, 0, 0, 1, 0, 0, 0};
+  launch_reduce_multi(part, nparts, pstride, s0, none, none, st);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
 int launch_reduce_parts2(const float* part, int nparts, int64_t pstride, int pld, int off1, float* out0, float* out1,
                          int C, int accumulate, hipStream_t st) {
-  RedSeg s0{out0, 0, pld, pld, C, C};
-  RedSeg s1{out1, off1, pld, pld, C, C};
-  RedSeg none{nullptr, 0, 0, 1, 0, 0};
-  launch_reduce_multi(part, nparts, pstride, s0, s1, none, accumulate, st);
+  RedSeg s0{out0, 0, pld, pld, C, C, accumulate};
+  RedSeg s1{out1, off1, pld, pld, C, C, accumulate};
+  RedSeg none{nullptr, 0, 0, 1, 0, 0, 0};
+  launch_reduce_multi(part, nparts, pstride, s0, s1, none, st);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
 }  // namespace gcl
 
 namespace {
+
+int gcl_ablate() {  // GCL_ABLATE: timing-only experiments (tools/ablate.sh); 0 unless set
+  static const int v = [] { const char* e = getenv("GCL_ABLATE"); return e ? atoi(e) : 0; }();
+  return v;
+}
 
 bool use_valu() {
   static int v = -1;
@@ -1161,7 +1170,7 @@ int launch_linear(const float* X, int64_t ldx, const float* in_slope, const floa
     { static bool lds_set = false;                                                                          \
       if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
     hipLaunchKernelGGL(kern, dim3(g.grid), dim3(g.waves * 64), g.lds, st, X, ldx, in_slope, W, ldw, trans, bias,  \
-                       Y, ldy, rows, K, N, Z, ldz, z_slope, slope_part, akind);                                   \
+                       Y, ldy, rows, K, N, Z, ldz, z_slope, slope_part, akind, gcl_ablate());                     \
   } while (0)
 #define GCL_LIN2(NS_, KT_)                 \
   do {                                     \
@@ -1466,13 +1475,24 @@ extern "C" int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W,
   GCL_CHECK_ARG(dy && W && x && dx && dW, "linear_bwd_all: null argument");
   GCL_CHECK_ARG(ws && ws_bytes >= gcl_linear_bwd_all_ws_bytes(rows, Fin, Fout), "linear_bwd_all: workspace too small");
   hipStream_t st = (hipStream_t)stream;
+  // every destination has its own accumulate bit: dW, db and colsum_dx usually belong to DIFFERENT
+  // parameters (colsum_dx is the bias gradient of the layer below) with different .grad states
+  const int acc_dw = (accumulate & GCL_ACC_DW) ? 1 : 0, acc_db = (accumulate & GCL_ACC_DB) ? 1 : 0,
+            acc_cs = (accumulate & GCL_ACC_COLSUM) ? 1 : 0;
   if (!fused_ok(dy, lddy, x, ldx, dx, lddx, Fin, Fout) || rows == 0) {
-    int rc = gcl_linear_bwd_dw(dy, lddy, x, ldx, in_slope, dW, db, rows, Fin, Fout, accumulate, ws, ws_bytes, stream);
+    int rc;
+    if (db && acc_db != acc_dw) {  // separate kernels share one flag between dW and db: split the call
+      rc = gcl_linear_bwd_dw(dy, lddy, x, ldx, in_slope, dW, nullptr, rows, Fin, Fout, acc_dw, ws, ws_bytes, stream);
+      if (rc) return rc;
+      rc = gcl_colsum(dy, lddy, rows, Fout, db, acc_db, ws, ws_bytes, stream);
+    } else {
+      rc = gcl_linear_bwd_dw(dy, lddy, x, ldx, in_slope, dW, db, rows, Fin, Fout, acc_dw, ws, ws_bytes, stream);
+    }
     if (rc) return rc;
     rc = gcl_linear_bwd_dx(dy, lddy, W, in_slope ? x : nullptr, ldx, in_slope, d_in_slope, dx, lddx, rows, Fin, Fout,
                            ws, ws_bytes, stream);
     if (rc) return rc;
-    if (colsum_dx) rc = gcl_colsum(dx, lddx, rows, Fin, colsum_dx, accumulate, ws, ws_bytes, stream);
+    if (colsum_dx) rc = gcl_colsum(dx, lddx, rows, Fin, colsum_dx, acc_cs, ws, ws_bytes, stream);
     return rc;
   }
   const int NO = (Fout + 31) / 32, NC = (Fin + 31) / 32;
@@ -1523,12 +1543,11 @@ extern "C" int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W,
   {
     // per-block record: [dW tile FoP*FiP | db FoP | colsum FiP]; one launch reduces all three
     const int64_t rec = (int64_t)FoP * FiP + FoP + FiP;
-    RedSeg s0{dW, 0, Fout * FiP, FiP, Fin, Fin};
-    RedSeg s1{db, FoP * FiP, db ? Fout : 0, FoP, Fout, 0};
-    RedSeg s2{colsum_dx, FoP * FiP + FoP, colsum_dx ? Fin : 0, FiP, Fin, 0};
+    RedSeg s0{dW, 0, Fout * FiP, FiP, Fin, Fin, acc_dw};
+    RedSeg s1{db, FoP * FiP, db ? Fout : 0, FoP, Fout, 0, acc_db};
+    RedSeg s2{colsum_dx, FoP * FiP + FoP, colsum_dx ? Fin : 0, FiP, Fin, 0, acc_cs};
     // + the slope partials (one extra block of the same launch)
-    launch_reduce_multi(part_dw, nblk, rec, s0, s1, s2, accumulate, st, want_slope ? part_sl : nullptr, nblk,
-                        d_in_slope);
+    launch_reduce_multi(part_dw, nblk, rec, s0, s1, s2, st, want_slope ? part_sl : nullptr, nblk, d_in_slope);
     GCL_CHECK_LAUNCH();
   }
   return GCL_OK;

@@ -101,10 +101,14 @@ class MLPFn(torch.autograd.Function):
             db = G.dst[bi]
             if k > 0:
                 # one fused launch: dz_{k-1}, dW_k, db_k, d(slope_{k-1})
-                dz = hip.linear_bwd_all(dz, W, inp, slope, G.dst[3 * k - 1], dW, db, None, G.acc[wi])
+                dz = hip.linear_bwd_all(dz, W, inp, slope, G.dst[3 * k - 1], dW, db, None, G.acc[wi], acc_db=G.acc[bi])
             elif ctx.needs_input_grad[0]:
                 # first layer with a differentiable input: dx, dW and db from one read of dz
-                dx = hip.linear_bwd_all(dz, W, inp, None, None, dW, db, None, G.acc[wi], act=hip.ACT_NONE)
+                dx = hip.linear_bwd_all(dz, W, inp, None, None, dW, db, None, G.acc[wi], acc_db=G.acc[bi],
+                                        act=hip.ACT_NONE)
+            elif db is not None and G.acc[bi] != G.acc[wi]:  # the dW kernel shares one flag between dW and db
+                hip.linear_bwd_dw(dz, inp, None, dW, None, G.acc[wi])
+                hip.colsum(dz, db, G.acc[bi])
             else:
                 hip.linear_bwd_dw(dz, inp, None, dW, db, G.acc[wi])
         if dx is not None:
@@ -210,23 +214,23 @@ class GCNStackFn(torch.autograd.Function):
             dh2 = hip.aggregate(graph, dp, None, transpose=True).view(B * n, -1)
             dW = G.dst[wi] if G.dst[wi] is not None else torch.zeros_like(params[wi])
             padded = pad is not None and k == L - 1
+            acc_w = G.acc[wi]
             if padded:  # gradient of the padded weight goes to a scratch, its first Fout rows to the parameter
-                W, dW_real, acc_real = pad[2], dW, G.acc[wi]
-                dW = torch.zeros_like(W)
-                G.acc[wi] = False
+                W, dW_real = pad[2], dW
+                dW = torch.empty_like(W)
+                acc_w = False  # the scratch is overwritten; every OTHER destination keeps its own flag
             if k > 0:
                 # one fused launch: dp_{k-1} (with PReLU'), dW_k, d(slope) and the bias gradient of
-                # conv k-1 (= column sums of dp_{k-1})
-                dp = hip.linear_bwd_all(dh2, W, inp, slope_t, dsl, dW, None, G.dst[2 * k - 1], G.acc[wi],
-                                        act=akind).view(B, n, -1)
+                # conv k-1 (= column sums of dp_{k-1}), which accumulates by ITS parameter's state
+                dp = hip.linear_bwd_all(dh2, W, inp, slope_t, dsl, dW, None, G.dst[2 * k - 1], acc_w,
+                                        acc_colsum=G.acc[2 * k - 1], act=akind).view(B, n, -1)
             elif ctx.needs_input_grad[0]:
-                dx = hip.linear_bwd_all(dh2, W, inp, None, None, dW, None, None, G.acc[wi],
+                dx = hip.linear_bwd_all(dh2, W, inp, None, None, dW, None, None, acc_w,
                                         act=hip.ACT_NONE).view(B, n, -1)
             else:
-                hip.linear_bwd_dw(dh2, inp, None, dW, None, G.acc[wi])
+                hip.linear_bwd_dw(dh2, inp, None, dW, None, acc_w)
             if padded:
-                G.acc[wi] = acc_real
-                dW_real.add_(dW[:pad[1]]) if acc_real else dW_real.copy_(dW[:pad[1]])
+                dW_real.add_(dW[:pad[1]]) if G.acc[wi] else dW_real.copy_(dW[:pad[1]])
         if dx is not None and ctx.squeeze:
             dx = dx[0]
         return (dx, None, None, None, None, None) + G.out()

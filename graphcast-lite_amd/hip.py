@@ -321,14 +321,26 @@ def dense_bwd_dw(dy, x, dW, db, accumulate: bool, act=ACT_NONE, slope=None):
 AGG_PROFILE = None
 
 
-def linear_bwd_all(dy, W, x, in_slope, d_in_slope, dW, db, colsum_dx, accumulate: bool, act=None):
-    """dx (pre-activation gradient) + dW (+ db, slope gradient, column sums of dx) in one call."""
+ACC_DW, ACC_DB, ACC_COLSUM = 1, 2, 4  # GCL_ACC_* bits of gcl_linear_bwd_all
+
+
+def linear_bwd_all(dy, W, x, in_slope, d_in_slope, dW, db, colsum_dx, acc_dW: bool, acc_db=None, acc_colsum=None,
+                   act=None):
+    """dx (pre-activation gradient) + dW (+ db, slope gradient, column sums of dx) in one call.
+    Each destination has its own accumulate flag (acc_db / acc_colsum default to acc_dW): dW, db and
+    colsum_dx are gradients of different parameters."""
+    acc_db = acc_dW if acc_db is None else acc_db
+    acc_colsum = acc_dW if acc_colsum is None else acc_colsum
     a = _act_of(act, in_slope)
     if a == ACT_SILU:  # the fused kernel knows PReLU only
-        dense_bwd_dw(dy, x, dW, db, accumulate, a, None)
+        if db is not None and bool(acc_db) != bool(acc_dW):
+            dense_bwd_dw(dy, x, dW, None, acc_dW, a, None)
+            colsum(dy, db, acc_db)
+        else:
+            dense_bwd_dw(dy, x, dW, db, acc_dW, a, None)
         dx = dense_bwd_dx(dy, W, x, a, None, None)
         if colsum_dx is not None:
-            colsum(dx, colsum_dx, accumulate)
+            colsum(dx, colsum_dx, acc_colsum)
         return dx
     rows, Fout = dy.shape
     Fin = W.shape[1]
@@ -337,7 +349,9 @@ def linear_bwd_all(dy, W, x, in_slope, d_in_slope, dW, db, colsum_dx, accumulate
     ws = workspace(nb, dy.device)
     _check(lib().gcl_linear_bwd_all(
         _p(dy), _ld(dy), _p(W), _p(x), _ld(x), _p(in_slope), _p(d_in_slope), _p(dx), Fin, _p(dW), _p(db),
-        _p(colsum_dx), rows, Fin, Fout, 1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()))
+        _p(colsum_dx), rows, Fin, Fout,
+        (ACC_DW if acc_dW else 0) | (ACC_DB if acc_db else 0) | (ACC_COLSUM if acc_colsum else 0),
+        ws.data_ptr(), ws.numel(), _stream()))
     return dx
 
 

@@ -365,12 +365,40 @@ class TrainStep:
         self.lat_weights, self.channel_mask, self.spatial_mask = lat_weights, channel_mask, spatial_mask
         self.use_residual, self.ar_steps, self.world = use_residual, ar_steps, world_size
         self.static_channels, self.forcing_channels = static_channels, forcing_channels
+        # use_graph=True: the caller REQUIRES the hipGraph path (a failed capture raises);
+        # use_graph=None: replay when the capture works, fall back to eager launches with a warning
+        self._graph_required = use_graph is True
         if use_graph is None:
             use_graph = os.environ.get("GCL_NO_GRAPH", "0") in ("0", "")
         self.use_graph = bool(use_graph)
         self._sparse = bool(getattr(model, "using_sparse_gat", False))
         self.split_finish = (world_size > 1) if split_finish is None else bool(split_finish or world_size > 1)
         self._graph, self._sX, self._sy, self._sloss, self._eager_calls = None, None, None, None, 0
+        self.capture_error = None
+        if world_size > 1:
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError(f"TrainStep(world_size={world_size}) needs an initialised torch.distributed process group")
+            if dist.get_world_size() != world_size:
+                raise RuntimeError(f"TrainStep(world_size={world_size}) but the process group has {dist.get_world_size()} ranks")
+            self.sync_from_rank0()
+
+    def sync_from_rank0(self):
+        """Only gradients are all-reduced, so replicas stay identical only if they START identical: rank 0's
+        parameters and Adam state are broadcast once (ranks built from different seeds or checkpoints
+        would otherwise diverge silently)."""
+        for t in (self.flat.flat, self.opt.m, self.opt.v, self.opt.step_dev):
+            dist.broadcast(t, src=0)
+
+    @property
+    def graph_active(self) -> bool:
+        """True while steps are being replayed from a captured hipGraph."""
+        return bool(self.use_graph and self._graph is not None)
+
+    @property
+    def launch_mode(self) -> str:
+        if self.graph_active:
+            return "hipGraph replay" + (" (fwd+bwd; all-reduce + Adam eager)" if self.split_finish else "")
+        return "eager" + (f" (capture failed: {self.capture_error})" if self.capture_error else "")
 
     def _fwd_bwd(self, X, y, threshold=0.0, epoch=0, batch_num=1):
         self.flat.zero_grad()
@@ -428,11 +456,16 @@ class TrainStep:
                 return self._eager(X, y, threshold, epoch, batch_num)
             try:
                 self._capture(X, y)
-            except Exception as e:  # capture is an optimisation, never a requirement
-                print(f"[TrainStep] hipGraph capture unavailable ({type(e).__name__}: {str(e)[:300]}); staying eager",
-                      flush=True)
+            except Exception as e:
+                self.capture_error = f"{type(e).__name__}: {str(e)[:300]}"
                 self.use_graph, self._graph = False, None
                 torch.cuda.synchronize()
+                if self._graph_required:  # the caller asked for the graph path explicitly: no silent degradation
+                    raise RuntimeError(f"TrainStep(use_graph=True): hipGraph capture failed ({self.capture_error})") from e
+                import warnings
+
+                warnings.warn(f"[TrainStep] hipGraph capture unavailable ({self.capture_error}); staying eager "
+                              f"(see .launch_mode / .graph_active)", RuntimeWarning)
                 return self._eager(X, y, threshold, epoch, batch_num)
             return self._replay()  # capture only records; the first replay performs this step
         if X.shape != self._sX.shape:

@@ -107,7 +107,13 @@ size_t gcl_linear_bwd_ws_bytes(int64_t rows, int32_t Fin, int32_t Fout);
 /* Whole backward of one dense transform in one call: dx (pre-activation gradient), dW, db (NULL: no
  * bias), the slope gradient, and optionally colsum_dx[c] (+)= sum_r dx[r,c] (the bias gradient of
  * the conv layer that produced x).  Uses ONE fused kernel (dY and x read once) when
- * Fout <= 64, Fin <= 96 and rows are 16-B aligned, else the three separate kernels. */
+ * Fout <= 64, Fin <= 96 and rows are 16-B aligned, else the three separate kernels.
+ * `accumulate` is a bit mask with ONE BIT PER DESTINATION (they belong to different parameters,
+ * whose gradients may be in different states): a set bit adds into that destination, a clear bit
+ * overwrites it.  *d_in_slope is always added to. */
+#define GCL_ACC_DW 1     /* dW */
+#define GCL_ACC_DB 2     /* db */
+#define GCL_ACC_COLSUM 4 /* colsum_dx */
 int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W, const float* x, int64_t ldx,
                        const float* in_slope, float* d_in_slope, float* dx, int64_t lddx, float* dW,
                        float* db, float* colsum_dx, int64_t rows, int32_t Fin, int32_t Fout,

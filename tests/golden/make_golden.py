@@ -21,6 +21,15 @@ Outputs (data only - arrays and numbers, no reference source text):
                                        and a flat (per-node coordinates) grid
   tests/golden/loss_vectors.npz        (pred, target, lat_w) -> loss, lat weights, threshold schedule
   tests/golden/config_parse.json       selected fields of the parsed reference configs
+  tests/golden/loader_vectors.npz      fp16 series + scalers -> TimeseriesChunkDataset.__getitem__ windows (grid and
+                                       flat layouts, every split), src/data/dataloader_chunked.py:33-223
+  tests/golden/mlp_vectors.npz         reference MLP (no LayerNorm, src/models.py:54-109): weights, input, output and
+                                       autograd gradients for two shapes
+  tests/golden/train_loop_vectors.npz  reference train_epoch / test (src/train.py:138-308) + spatial_corr (:114-130)
+                                       driven with a stub model (a fixed per-node linear map with `.obs_window`):
+                                       AR 1..3, static / forcing channels, masks -> losses, gradients, Adam-updated
+                                       weights, (loss, ACC, RMSE) of the evaluation loop
+  tests/golden/assemble_vectors.npz    WeatherPrediction._preprocess_input (src/models.py:776-806) on a stub `self`
 """
 import hashlib
 import json
@@ -225,7 +234,192 @@ def main():
         )
     with open(os.path.join(HERE, "config_parse.json"), "w") as fh:
         json.dump(parsed, fh, indent=1, sort_keys=True)
+    _loader_vectors()
+    _mlp_vectors()
+    _train_loop_vectors()
+    _assemble_vectors()
     print("golden fixtures written to", HERE)
+
+
+class StubModel(torch.nn.Module):
+    """What src/train.py needs from a model: `.obs_window` and `model(X=, attention_threshold=, epoch=,
+    batch_num=) -> [N, G, C]`.  A fixed per-node linear map of the flattened window (+ tanh so that
+    the AR gradient is not trivially linear).  Test scaffolding of THIS repo, not reference code."""
+
+    def __init__(self, obs, C, seed):
+        super().__init__()
+        self.obs_window = obs
+        g = torch.Generator().manual_seed(seed)
+        self.W = torch.nn.Parameter(0.3 * torch.randn(C, obs * C, generator=g))
+        self.b = torch.nn.Parameter(0.1 * torch.randn(C, generator=g))
+
+    def forward(self, X, attention_threshold=0.0, **kw):
+        return 0.5 * torch.tanh(X @ self.W.t() + self.b)
+
+
+def _loader_vectors():
+    """Run the reference's TimeseriesChunkDataset on small synthetic fp16 series written to a temp dir."""
+    import tempfile
+
+    from src.data.dataloader_chunked import TimeseriesChunkDataset
+
+    out = {}
+    rs = np.random.RandomState(11)
+    with tempfile.TemporaryDirectory() as d:
+        # regular grid (T, lon, lat, Ct) as a headerless memmap + dataset_info.json
+        T, n_lon, n_lat, Ct, C = 14, 6, 5, 7, 5
+        series = (rs.randn(T, n_lon, n_lat, Ct) * 3 + 1).astype(np.float16)
+        mean, std = rs.randn(Ct).astype(np.float64), (0.5 + rs.rand(Ct)).astype(np.float64)
+        gd = os.path.join(d, "grid")
+        os.makedirs(gd)
+        series.tofile(os.path.join(gd, "data.npy"))
+        np.savez(os.path.join(gd, "scalers.npz"), mean=mean, std=std, n=T)
+        with open(os.path.join(gd, "dataset_info.json"), "w") as fh:
+            json.dump({"n_time": T, "n_lon": n_lon, "n_lat": n_lat, "n_feat": Ct}, fh)
+        out.update(grid_series=series, grid_mean=mean, grid_std=std, grid_C=C)
+        for split in ("train", "test", "val", "test_only", "all"):
+            ds = TimeseriesChunkDataset(gd, obs_window=2, pred_steps=3, split=split, n_features=C)
+            out[f"grid_{split}_len"] = len(ds)
+            out[f"grid_{split}_t0"] = np.array([t for _, t in ds._sample_indices], dtype=np.int64)
+            if len(ds):
+                X, Y = zip(*[ds[i] for i in range(len(ds))])
+                out[f"grid_{split}_X"] = torch.stack(X).numpy()
+                out[f"grid_{split}_Y"] = torch.stack(Y).numpy()
+        # flat nodes (T, N, Ct)
+        T2, N, Ct2 = 9, 23, 4
+        fseries = (rs.randn(T2, N, Ct2) * 2).astype(np.float16)
+        fmean, fstd = rs.randn(Ct2).astype(np.float64), (0.5 + rs.rand(Ct2)).astype(np.float64)
+        fd = os.path.join(d, "flat")
+        os.makedirs(fd)
+        fseries.tofile(os.path.join(fd, "data.npy"))
+        np.savez(os.path.join(fd, "scalers.npz"), mean=fmean, std=fstd, n=T2)
+        with open(os.path.join(fd, "dataset_info.json"), "w") as fh:
+            json.dump({"n_time": T2, "n_nodes": N, "n_feat": Ct2, "flat": True}, fh)
+        ds = TimeseriesChunkDataset(fd, obs_window=3, pred_steps=1, split="all")
+        X, Y = zip(*[ds[i] for i in range(len(ds))])
+        out.update(flat_series=fseries, flat_mean=fmean, flat_std=fstd, flat_all_X=torch.stack(X).numpy(),
+                   flat_all_Y=torch.stack(Y).numpy(),
+                   flat_all_t0=np.array([t for _, t in ds._sample_indices], dtype=np.int64))
+        # legacy multi-chunk layout (chunk_*.npy with headers): windows never cross a chunk boundary
+        cd = os.path.join(d, "chunks")
+        os.makedirs(cd)
+        c0, c1 = series[:6], series[6:]
+        np.save(os.path.join(cd, "chunk_0.npy"), c0)
+        np.save(os.path.join(cd, "chunk_1.npy"), c1)
+        np.savez(os.path.join(cd, "scalers.npz"), mean=mean, std=std, n=T)
+        ds = TimeseriesChunkDataset(cd, obs_window=2, pred_steps=1, split="all", n_features=C)
+        out["chunks_all_index"] = np.array(ds._sample_indices, dtype=np.int64)
+        X, Y = zip(*[ds[i] for i in range(len(ds))])
+        out["chunks_all_X"], out["chunks_all_Y"] = torch.stack(X).numpy(), torch.stack(Y).numpy()
+    np.savez_compressed(os.path.join(HERE, "loader_vectors.npz"), **out)
+
+
+def _mlp_vectors():
+    """The reference's pure-torch MLP (no LayerNorm: PyG's is absent) with saved weights."""
+    from src.config import MLPBlock
+    from src.models import MLP
+
+    out = {}
+    for tag, (rows, fin, hidden, fout) in {"enc": (300, 72, [48, 48], 64), "dec": (257, 64, [64, 64], 64),
+                                           "odd": (50, 19, [33], 19), "single": (64, 20, [], 12)}.items():
+        torch.manual_seed(5)
+        m = MLP(MLPBlock(mlp_hidden_dims=hidden, output_dim=fout, use_layer_norm=False), input_dim=fin)
+        g = torch.Generator().manual_seed(17)
+        with torch.no_grad():
+            for p in m.parameters():
+                if p.numel() == 1:
+                    p.fill_(0.1 + 0.3 * float(torch.rand(1, generator=g)))  # distinct PReLU slopes
+        x = torch.randn(rows, fin, generator=g, requires_grad=True)
+        dy = torch.randn(rows, fout, generator=g)
+        y = m(x)
+        y.backward(dy)
+        out[f"{tag}_x"], out[f"{tag}_dy"], out[f"{tag}_y"], out[f"{tag}_dx"] = (x.detach().numpy(), dy.numpy(),
+                                                                              y.detach().numpy(), x.grad.numpy())
+        out[f"{tag}_keys"] = np.array(list(m.state_dict().keys()))
+        for k, v in m.state_dict().items():
+            out[f"{tag}_w_{k}"] = v.numpy()
+        for k, p in m.named_parameters():
+            out[f"{tag}_g_{k}"] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "mlp_vectors.npz"), **out)
+
+
+def _train_loop_vectors():
+    from src.train import (build_boundary_mask, get_lat_weights, spatial_corr, test, train_epoch)
+
+    out = {}
+    n_lat, n_lon, obs, C = 6, 8, 2, 5
+    G = n_lat * n_lon
+    gen = torch.Generator().manual_seed(101)
+    batches = [(torch.randn(2, G, obs * C, generator=gen), 0.7 * torch.randn(2, G, 3 * C, generator=gen)) for _ in range(3)]
+    out["X"] = torch.stack([b[0] for b in batches]).numpy()
+    out["Y"] = torch.stack([b[1] for b in batches]).numpy()
+    lat_w = get_lat_weights(n_lat, n_lon, "cpu")
+    chan = torch.tensor([1.0, 1.0, 0.0, 1.0, 0.5])
+    smask = build_boundary_mask(n_lon, n_lat, 1, "cpu")
+    out.update(lat_w=lat_w.numpy(), chan_mask=chan.numpy(), spatial_mask=smask.numpy(), obs=obs, C=C, n_lat=n_lat, n_lon=n_lon)
+    cases = {
+        "ar1_plain": dict(current_ar_steps=1),
+        "ar1_lat": dict(current_ar_steps=1, lat_weights=lat_w),
+        "ar2_static_forcing": dict(current_ar_steps=2, lat_weights=lat_w, channel_mask=chan, static_channels=[2],
+                                   forcing_channels=[4]),
+        "ar3_all": dict(current_ar_steps=3, lat_weights=lat_w, channel_mask=chan, spatial_mask=smask,
+                        static_channels=[2], forcing_channels=[0, 4]),
+        "ar3_noresidual": dict(current_ar_steps=3, lat_weights=lat_w, static_channels=[2], forcing_channels=[4],
+                               use_residual=False),
+        "ar5_capped": dict(current_ar_steps=5, lat_weights=lat_w),  # more steps asked than targets exist: runs 3
+    }
+    out["cases"] = np.array(list(cases))
+    for tag, kw in cases.items():
+        m = StubModel(obs, C, seed=9)
+        if tag == "ar1_plain":
+            out["W0"], out["b0"] = m.W.detach().numpy().copy(), m.b.detach().numpy().copy()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+        losses = [train_epoch(m, batches, opt, None, "cpu", 0.0, ep, **kw) for ep in range(2)]
+        out[f"{tag}_epoch_losses"] = np.array(losses, dtype=np.float64)
+        out[f"{tag}_W"], out[f"{tag}_b"] = m.W.detach().numpy(), m.b.detach().numpy()
+        out[f"{tag}_gW_last"], out[f"{tag}_gb_last"] = m.W.grad.numpy().copy(), m.b.grad.numpy().copy()
+        # gradient of the FIRST batch at the initial weights (no optimiser in between)
+        m0 = StubModel(obs, C, seed=9)
+        o0 = torch.optim.SGD(m0.parameters(), lr=0.0)
+        out[f"{tag}_loss_first"] = train_epoch(m0, batches[:1], o0, None, "cpu", 0.0, 0, **kw)
+        out[f"{tag}_gW_first"], out[f"{tag}_gb_first"] = m0.W.grad.numpy().copy(), m0.b.grad.numpy().copy()
+    # evaluation loop (one-step, carry-forward, weighted MSE / spatial ACC / raw RMSE)
+    m = StubModel(obs, C, seed=9)
+    ev = {
+        "eval_plain": dict(),
+        "eval_all": dict(lat_weights=lat_w, spatial_mask=smask, channel_mask=chan, static_channels=[2], forcing_channels=[0, 4]),
+        "eval_noresidual": dict(lat_weights=lat_w, static_channels=[2], use_residual=False),
+    }
+    for tag, kw in ev.items():
+        out[tag] = np.array(test(m, batches, None, "cpu", **kw), dtype=np.float64)
+    # single-target batches (y is [N, G, C]: the `total_target_steps == 1` branch)
+    b1 = [(X, Y[..., :C].contiguous()) for X, Y in batches]
+    out["eval_single_target"] = np.array(test(m, b1, None, "cpu", lat_weights=lat_w), dtype=np.float64)
+    # spatial_corr on its own
+    p, t = torch.randn(3, G, C, generator=gen), torch.randn(3, G, C, generator=gen)
+    out["sc_pred"], out["sc_true"] = p.numpy(), t.numpy()
+    out["sc_batched"] = spatial_corr(p, t)
+    out["sc_sample0"] = spatial_corr(p[0], t[0])
+    out["sc_excl"] = spatial_corr(p, t, exclude_channels=[1, 3])
+    out["sc_const"] = spatial_corr(torch.ones(G, C), t[0])  # zero variance: the +1e-8 guard
+    np.savez_compressed(os.path.join(HERE, "train_loop_vectors.npz"), **out)
+
+
+def _assemble_vectors():
+    from src.models import WeatherPrediction
+
+    out = {}
+    gen = torch.Generator().manual_seed(3)
+    for tag, (G, M, Cdyn, Cs, product) in {"a": (37, 12, 10, 6, False), "b": (16, 40, 7, 6, True)}.items():
+        stub = types.SimpleNamespace(
+            init_grid_features=torch.randn(G, Cs, generator=gen), init_mesh_features=torch.randn(M, Cs, generator=gen),
+            num_features=Cdyn, total_feature_size=Cdyn if not product else 3 * Cdyn, use_product_graph=product,
+            _num_mesh_nodes=M, device="cpu")
+        x = torch.randn(G, Cdyn, generator=gen)
+        y = WeatherPrediction._preprocess_input(stub, x)
+        out[f"{tag}_x"], out[f"{tag}_gs"], out[f"{tag}_ms"], out[f"{tag}_out"] = (
+            x.numpy(), stub.init_grid_features.numpy(), stub.init_mesh_features.numpy(), y.numpy())
+    np.savez_compressed(os.path.join(HERE, "assemble_vectors.npz"), **out)
 
 
 if __name__ == "__main__":

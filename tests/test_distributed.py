@@ -127,3 +127,128 @@ def test_sparse_gat_prune_broadcast_c2(tmp_path):
     assert torch.equal(e0, torch.arange(10, dtype=torch.int64).view(2, 5)) and torch.equal(e0, e1)
     x = torch.zeros(2, 3, dtype=torch.int64)
     assert _broadcast_edges_from_rank0(x) is x  # single process: untouched
+
+
+# ------------------------------------------------------------------------------------------------
+# bench.py's own launcher (CPU, gloo): `python bench.py --gpus N` without torchrun must start N real
+# ranks - or fail - and report the world size the process group has, never args.gpus.
+# ------------------------------------------------------------------------------------------------
+def _run_bench(args, env_extra, timeout=300):
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, lines
+
+
+def test_bench_launcher_spawns_real_ranks():
+    r, lines = _run_bench(["--gpus", "2"], {"GCL_BENCH_SELFTEST": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1  # ONE line, from rank 0
+    assert lines[0] == {"selftest": True, "n_gpus": 2, "rank_sum": 3.0, "spawned": True}
+    r, lines = _run_bench(["--gpus", "3"], {"GCL_BENCH_SELFTEST": "1"})
+    assert r.returncode == 0 and lines[0]["n_gpus"] == 3 and lines[0]["rank_sum"] == 6.0
+
+
+def test_bench_never_reports_more_gpus_than_ranks():
+    """Without a launcher and without enough devices the run FAILS (no JSON line); a launcher that started
+    a different number of ranks than --gpus says is refused as well."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    r, lines = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
+    assert r.returncode != 0 and not lines
+    assert "refusing" in r.stderr
+    r, lines = _run_bench(["--gpus", "2"], {"GCL_BENCH_SELFTEST": "1", "WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and not lines and "WORLD_SIZE=1" in r.stderr
+    # a failing rank takes the whole launch down with a non-zero code
+    r, lines = _run_bench(["--gpus", "2"], {"GCL_BENCH_SELFTEST": "1", "GCL_DIST_BACKEND": "no_such_backend"})
+    assert r.returncode != 0 and not lines
+
+
+# ------------------------------------------------------------------------------------------------
+# TrainStep with world_size 2 on the GPU box: two gloo ranks sharing device 0 (tests/helpers/dp_rank.py)
+# against the single-process step on the global batch.
+# ------------------------------------------------------------------------------------------------
+def _spawn_dp(tmp_path, steps, seed_mode, use_graph):
+    import subprocess
+    import sys
+
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "helpers", "dp_rank.py"), str(tmp_path),
+                                       str(steps), seed_mode, "1" if use_graph else "0"], env=env))
+    codes = [p.wait(timeout=900) for p in procs]
+    assert codes == [0, 0], codes
+    return torch.load(os.path.join(tmp_path, "dp_rank0.pt"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed_mode,use_graph", [("same", False), ("different", True)])
+def test_two_rank_train_step_equals_global_batch_step(tmp_path, seed_mode, use_graph):
+    """TrainStep(world_size=2): batch shards, ONE all-reduce of the flat gradient bucket, 1/world folded into
+    Adam - after 4 optimiser steps the replicas equal the single-process TrainStep on the global batch.
+    With `different` seeds per rank only TrainStep's broadcast of rank 0's state makes that true; with
+    `use_graph` the forward+backward is replayed from a hipGraph and the collective + Adam follow eagerly."""
+    sys_path = os.path.join(ROOT, "tests", "helpers")
+    import sys
+
+    sys.path.insert(0, sys_path)
+    import dp_rank
+    from graphcast_lite_amd.train import TrainStep, get_lat_weights
+
+    got = _spawn_dp(tmp_path, 4, seed_mode, use_graph)
+    cfg, m = dp_rank.build(42)  # rank 0's seed
+    step = TrainStep(m, lr=1e-3, lat_weights=get_lat_weights(32, 64, "cuda:0"), use_graph=False)
+    X, y = dp_rank.global_batch(m._num_grid_nodes)
+    Xd, yd = X.cuda(), y.cuda()
+    for i in range(4):
+        step(Xd * (1 + 0.01 * i), yd)
+    assert got["t"] == step.opt.t == 4
+    for k, v in m.named_parameters():
+        a, b = got["params"][k].double(), v.detach().cpu().double()
+        # 4 Adam steps: the normalised update g / sqrt(v) amplifies the fp32 summation-order difference between
+        # "2 ranks x 2 samples, then all-reduce" and "4 samples" (same bar as the torch-Adam comparison)
+        assert float((a - b).norm()) <= 1e-4 * float(b.norm()) + 1e-9, k
+    if use_graph:
+        assert got["launch_mode"].startswith("hipGraph replay")
+
+
+@pytest.mark.gpu
+def test_train_step_raises_when_requested_graph_cannot_be_captured(monkeypatch):
+    """use_graph=True is a requirement (RuntimeError on a failed capture); use_graph=None degrades to eager
+    launches with a RuntimeWarning and says so in .launch_mode."""
+    import sys
+    import warnings
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "helpers"))
+    import dp_rank
+    from graphcast_lite_amd import train as TR
+
+    cfg, m = dp_rank.build(42)
+    X, y = dp_rank.global_batch(m._num_grid_nodes, 2)
+    Xd, yd = X.cuda(), y.cuda()
+
+    def boom(self, X, y):
+        raise RuntimeError("capture refused (test)")
+
+    monkeypatch.setattr(TR.TrainStep, "_capture", boom)
+    s1 = TR.TrainStep(m, use_graph=True)
+    s1(Xd, yd), s1(Xd, yd)
+    with pytest.raises(RuntimeError, match="capture failed"):
+        s1(Xd, yd)
+    cfg, m2 = dp_rank.build(42)
+    s2 = TR.TrainStep(m2, use_graph=None)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for _ in range(4):
+            s2(Xd, yd)
+    assert any("capture unavailable" in str(x.message) for x in w)
+    assert not s2.graph_active and s2.launch_mode.startswith("eager (capture failed")

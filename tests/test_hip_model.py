@@ -589,6 +589,38 @@ def test_autoregressive_training_step_parity(name):
     assert s1.use_graph and s1._graph is not None
 
 
+@pytest.mark.parametrize("name,levels", [("baseline", [1, 2]), ("demo_low", [3]), ("wb2_512x256_19f_ar", [1, 2])])
+def test_ar_gradients_accumulate_in_flat_bucket(name, levels):
+    """The decoder backward runs once per AR step inside ONE loss.backward() and every run ACCUMULATES into
+    the live `.grad` slices of the flat bucket (TrainStep).  Each destination of the fused backward has its
+    own accumulate flag: the bias gradient of conv k-1 (column sums of dX) must not follow the flag of the
+    width-padded dW scratch of the last conv (the round-1 bug: it kept only the last-run contribution)."""
+    from graphcast_lite_amd.train import TrainStep, get_lat_weights
+
+    cfg, m, o = make_pair(name, levels)
+    G, F = m._num_grid_nodes, cfg.data.num_features_used
+    g = torch.Generator().manual_seed(33)
+    obs = m.obs_window
+    X = torch.randn(2, G, obs * F, generator=g)
+    y = torch.randn(2, G, 3 * F, generator=g) * 0.5
+    static, forcing = [F - 1], [0, 2]
+    lw, lwd = T.get_lat_weights(32, 64), get_lat_weights(32, 64, DEV)
+    lo = T.train_step_loss(o, X, y, lat_weights=lw, ar_steps=3, static_channels=static, forcing_channels=forcing)
+    lo.backward()
+    step = TrainStep(m, lr=1e-3, lat_weights=lwd, ar_steps=3, static_channels=static, forcing_channels=forcing,
+                     use_graph=False)
+    for rep in range(2):  # twice: the second call starts from a zeroed, EXISTING bucket again
+        lh = step._fwd_bwd(X.to(DEV), y.to(DEV))
+        assert rel(lh, lo) < 1e-5
+        og = dict(o.named_parameters())
+        for n_, p in m.named_parameters():
+            if og[n_].grad is None:
+                continue
+            assert p.grad.data_ptr() >= step.flat.grad.data_ptr()  # the bucket slice, accumulated in place
+            e = rel(p.grad, og[n_].grad)
+            assert e < 2e-4, f"{name} rep {rep}: gradient of {n_} rel {e:.3e}"
+
+
 @pytest.mark.parametrize("flat", [False, True])
 def test_regional_model_parity(flat):
     """The regional arrangement of the region_* experiments (src/main.py:146-173): a 61x41 grid over

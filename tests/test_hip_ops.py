@@ -92,6 +92,27 @@ def test_linear_bwd_all(hip, rows, Fin, Fout, with_slope):
     assert rel(dW2, W.grad) < 2e-5 and rel(db2, b.grad) < 2e-5
 
 
+@pytest.mark.parametrize("rows,Fin,Fout", [(1000, 64, 64), (300, 48, 36), (129, 72, 48), (700, 128, 128)])
+def test_linear_bwd_all_accumulate_bits(hip, rows, Fin, Fout):
+    """dW, db and colsum_dx belong to different parameters: each has its own accumulate bit
+    (GCL_ACC_DW / GCL_ACC_DB / GCL_ACC_COLSUM), on the fused kernel and on the fallback."""
+    x, W, dy = rnd(rows, Fin, seed=1), rnd(Fout, Fin, seed=2, scale=0.2), rnd(rows, Fout, seed=4)
+    a = torch.tensor([0.25])
+    xr, Wr, ar = x.clone().requires_grad_(), W.clone().requires_grad_(), a.clone().requires_grad_()
+    br = torch.zeros(Fout, requires_grad=True)
+    (P.prelu(xr, ar) @ Wr.t() + br).backward(dy)
+    xd, Wd, dyd, ad = x.to(DEV), W.to(DEV), dy.to(DEV), a.to(DEV)
+    for bits in range(8):
+        acc = [bool(bits & 1), bool(bits & 2), bool(bits & 4)]
+        dW, db, cs = (torch.full((Fout, Fin), 3.0, device=DEV), torch.full((Fout,), 5.0, device=DEV),
+                      torch.full((Fin,), 7.0, device=DEV))
+        hip.linear_bwd_all(dyd, Wd, xd, ad, torch.zeros(1, device=DEV), dW, db, cs, acc[0], acc_db=acc[1],
+                           acc_colsum=acc[2])
+        assert rel(dW - (3.0 if acc[0] else 0.0), Wr.grad) < 2e-5, bits
+        assert rel(db - (5.0 if acc[1] else 0.0), br.grad) < 2e-5, bits
+        assert rel(cs - (7.0 if acc[2] else 0.0), xr.grad.sum(0)) < 1e-4, bits
+
+
 def test_linear_mfma_equals_valu(hip, monkeypatch):
     """The fp32 MFMA path and the plain VALU path of the same entry point agree (both fp32 FMA chains)."""
     import os
