@@ -82,6 +82,7 @@ struct gcl_graph {
   int32_t *ecol = nullptr, *tecol = nullptr, *teslot = nullptr;  // teslot: forward slot of a transposed prefix edge
   float *ew = nullptr, *tew = nullptr;
   int32_t ell_width = 8, tell_width = 8;  // how many prefix entries the kernels read unconditionally
+  int32_t ell_cover = 8, tell_cover = 8;  // smallest of {2,4,8} covering >= 98 % of the rows (the one-kernel GCN layer)
   // rows with more than kHeavy edges: skipped by the row-group kernel, done by one block each
   int32_t *heavy = nullptr, *theavy = nullptr;
   int32_t n_heavy = 0, n_theavy = 0;

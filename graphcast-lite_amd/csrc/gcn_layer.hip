@@ -1,0 +1,576 @@
+// One GCNConv layer per launch, aggregate-first (src/models.py:419; backward of the same layer):
+//
+//   forward   y[b,i,:]  = (sum_{e in row i} w_e act(x[b, col_e, :])) W^T + bias
+//   backward  dh        = A_hat^T dp                       (gathered through the sender-sorted CSR)
+//             dx[b,i,:] = (dh[b,i,:] W) * act'(x[b,i,:])   dW += dh^T act(x)   cs += colsum(dx)   dslope += ...
+//
+// A_hat (act(X) W^T) = (A_hat act(X)) W^T, so aggregating the INPUT rows first keeps the intermediate
+// h = act(X) W^T out of memory altogether: per layer and direction the linear + aggregate pair of round 1
+// moved 2 x (read + write) of [B, n, F]; this kernel moves one read (the gather, mostly L2 hits) and one
+// write.  Design (MI355X):
+//   * WAVE-INDEPENDENT pipelines.  A wave owns 32 destination rows at a time ("wave tile"): it gathers and
+//     sums their neighbour rows into registers (16 lanes x float4 per row, ELL prefix -> up to 8 rows in
+//     flight per lane), drops the aggregated 32 x K tile into ITS OWN LDS region, runs the exact-fp32
+//     v_mfma_f32_32x32x2_f32 chain against the block's weight panel, transposes the result through the
+//     same LDS region and writes whole 16-byte row segments.  There is no block barrier after the weight
+//     panel is staged: waves drift apart, so one wave's MFMA chain overlaps the other waves' gathers
+//     and stores (a block-synchronous version runs its memory and matrix phases back to back).
+//   * 12 waves (one 768-thread block) per CU: 118 KB of LDS, <= 168 VGPRs.
+//   * XCD-aware persistent schedule: the blocks of XCD group g (blockIdx & 7) walk the samples
+//     b = g, g+8, ... so one sample's x (2.6 MB at 64x32) stays in one 4 MiB L2 while its ~7x neighbour
+//     re-reads happen.  Placement is a speed choice only.
+//   * Rows with more in-edges than the ELL prefix finish in a per-tile fix-up loop (read-modify-write of
+//     the wave's LDS tile) so the main path stays branch-free; sums keep PyG edge order either way.
+// Shapes: Fin % 4 == 0, Fin <= 64, Fout <= 64, graphs without heavy rows (in-degree <= 64).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned kOOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int64_t nbytes) {
+  const int64_t cap = 0x7FFFFF00;
+  const int n = (int)(nbytes < 0 ? 0 : (nbytes > cap ? cap : nbytes));
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+}
+__device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v) {
+  u32x4 u = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z),
+             __builtin_bit_cast(unsigned, v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, off, 0, 0);
+}
+__device__ float4 gl_zero4[1];
+
+__device__ __forceinline__ int d_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+template <int ACT>
+__device__ __forceinline__ float act_t(float x, float a) {
+  if (ACT == gcl::kActPrelu) return x > 0.f ? x : a * x;
+  if (ACT == gcl::kActSilu) return gcl::silu_f(x);
+  return x;
+}
+
+// Persistent schedule of one wave: work items are (sample, 32-row tile) pairs; the wave walks
+// q = first, first + stride, ... in its item space.  (s, rt) is advanced incrementally - no division per tile.
+struct Sched {
+  int xcd_map, nRT, s, rt, ds, drt, xg;
+  int64_t left;  // items left for this wave, including the current one
+  __device__ __forceinline__ void init(int B_, int nRT_, int nwaves) {
+    nRT = nRT_;
+    const int wave = threadIdx.x >> 6;
+    xcd_map = (B_ >= gcl::kNumXCD) && ((gridDim.x & (gcl::kNumXCD - 1)) == 0);
+    unsigned first, stride, items;
+    if (xcd_map) {
+      xg = blockIdx.x & (gcl::kNumXCD - 1);
+      const int nsx = (B_ - xg + gcl::kNumXCD - 1) / gcl::kNumXCD;  // samples xg, xg+8, ...
+      items = (unsigned)nsx * (unsigned)nRT_;
+      first = (blockIdx.x >> 3) * nwaves + wave;
+      stride = (gridDim.x >> 3) * nwaves;
+    } else {
+      xg = 0;
+      items = (unsigned)B_ * (unsigned)nRT_;
+      first = blockIdx.x * nwaves + wave;
+      stride = gridDim.x * nwaves;
+    }
+    s = first / (unsigned)nRT_;
+    rt = first - s * nRT_;
+    ds = stride / (unsigned)nRT_;
+    drt = stride - ds * nRT_;
+    left = first < items ? (int64_t)((items - 1 - first) / stride) + 1 : 0;
+  }
+  __device__ __forceinline__ int sample() const { return xcd_map ? xg + gcl::kNumXCD * s : s; }
+  __device__ __forceinline__ int row0() const { return rt * 32; }
+  __device__ __forceinline__ void advance() {
+    s += ds;
+    rt += drt;
+    if (rt >= nRT) {
+      rt -= nRT;
+      s += 1;
+    }
+    left -= 1;
+  }
+};
+
+// Stage a [NJ*32][KP] panel  P[j][k] = (j < N && k < K) ? W[TR ? k*ldw + j : j*ldw + k] : 0  (8 loads in flight)
+template <bool TR>
+__device__ __forceinline__ void stage_panel(float* Wl, const float* __restrict__ W, int ldw, int N, int K, int NJ32,
+                                            int KE, int KP) {
+  const int NT = blockDim.x, tid = threadIdx.x;
+  const int total = NJ32 * KE;
+  for (int base = 0; base < total; base += NT * 8) {
+    float wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * NT + tid;
+      const int j = idx / KE, k = idx - j * KE;
+      const bool ok = (idx < total) && (j < N) && (k < K);
+      const float* src = ok ? (TR ? W + (int64_t)k * ldw + j : W + (int64_t)j * ldw + k)
+                            : reinterpret_cast<const float*>(gl_zero4);
+      wv[u] = *src;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * NT + tid;
+      const int j = idx / KE, k = idx - j * KE;
+      if (idx < total) Wl[j * KP + k] = wv[u];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gather-aggregate the wave's 32 destination rows [r0, r0+32) of one sample into its LDS tile
+//     At[i][c] = sum_{e in row r0+i} w_e act(Hb[col_e][c]),     i < 32, c < K.
+// Lane = (row slot sub = lane / 16, channels 4 * (lane % 16) .. +3); 8 passes of 4 rows.
+//   * The tile's metadata - rowptr[33], the ELL prefix columns and weights of its 32 rows (1 KB each,
+//     contiguous in memory) - is fetched with ONE coalesced load per array a tile ahead (TileMeta, held in
+//     9 registers meanwhile) and parked in the wave's LDS region; a pass reads its row's 8 (col, w) pairs
+//     from there as broadcast 16-byte LDS reads: no per-pass index loads, no cross-lane shuffles.
+//   * Branch-free passes: the row loads of pass p+1 are issued before pass p is summed, every LDS write is
+//     unconditional (lanes beyond K write to a sink slot), so the compiler emits counted vmcnt waits.
+//   * Rows with more edges than the ELL prefix are completed afterwards by a fix-up loop over the CSR
+//     (read-modify-write of the tile, 4 loads in flight); sums keep PyG edge order (prefix, then the rest).
+// Rows past n aggregate row n-1 (never stored).
+// Per-wave LDS region (floats): tile / output staging [TILE_F] | sink [64] | rowptr [36] | ecol [256] | ew [256]
+// ---------------------------------------------------------------------------------------------
+constexpr int kStagger = 2;  // x s_sleep(64) = 2 x 4096 cycles per wave group
+constexpr int kSinkF = 64, kRpF = 36, kMetaF = kRpF + 2 * 32 * gcl::kEll;
+
+struct TileMeta {  // next tile's metadata in flight
+  int4 ec;
+  float4 ewv;
+  int rp;
+};
+
+__device__ __forceinline__ TileMeta meta_issue(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ecol,
+                                               const float* __restrict__ ew, int r0, int n) {
+  const int lane = threadIdx.x & 63;
+  int row = r0 + (lane >> 1);  // lane covers half (4 entries) of one row's prefix
+  row = row < n ? row : n - 1;
+  row = row < 0 ? 0 : row;
+  TileMeta m;
+  m.ec = *reinterpret_cast<const int4*>(ecol + (int64_t)row * gcl::kEll + (lane & 1) * 4);
+  m.ewv = *reinterpret_cast<const float4*>(ew + (int64_t)row * gcl::kEll + (lane & 1) * 4);
+  int rr = r0 + (lane < 33 ? lane : 32);
+  rr = rr < n ? rr : n;
+  rr = rr < 0 ? 0 : rr;
+  m.rp = rowptr[rr];
+  return m;
+}
+
+__device__ __forceinline__ void meta_commit(float* __restrict__ Mt, const TileMeta& m) {
+  const int lane = threadIdx.x & 63;
+  int* rp = reinterpret_cast<int*>(Mt);
+  int* ec = rp + kRpF;
+  float* ewl = Mt + kRpF + 32 * gcl::kEll;
+  *reinterpret_cast<int4*>(ec + lane * 4) = m.ec;
+  *reinterpret_cast<float4*>(ewl + lane * 4) = m.ewv;
+  rp[lane < 33 ? lane : 33] = m.rp;  // lanes 33..63 land on a spare slot
+}
+
+// One sample's rows are addressed as (wave-uniform base) + 32-bit byte offset.  (Not raw_buffer_load_b128: hipcc of
+// ROCm 7.2 lowers that builtin to ONE dword load whose value is replicated into all four components.)
+typedef __attribute__((address_space(1))) const char gchar;  // global address space: keeps the loads global_load, not flat_load
+struct RowBase {
+  gchar* p;
+};
+__device__ __forceinline__ RowBase sample_rows(const float* base) {
+  const uint64_t q = reinterpret_cast<uint64_t>(base);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
+  return RowBase{(gchar*)(((uint64_t)hi << 32) | lo)};
+}
+__device__ __forceinline__ float4 row_ld4(RowBase r, unsigned off) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) const v4f gv4f;
+  const v4f v = *(gv4f*)(r.p + off);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+// max(x, 0) as exactly one VALU instruction (fmaxf / fmed3 are lowered to a canonicalising v_max plus the max)
+__device__ __forceinline__ float relu1(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// one neighbour row into the running sums:  a += w * act(v)
+//   PReLU: act(x) = s x + (1 - s) max(x, 0)  ->  a += (w s) x + (w (1 - s)) max(x, 0): 4 v_max + 4 packed FMAs per
+//   float4 instead of compare / select / multiply per element (the SIMD's VALU issue is the scarce resource here:
+//   an fp32 MFMA holds it for its whole duration, so every VALU instruction of the gather is paid in full)
+template <int ACT>
+__device__ __forceinline__ void row_fma(f32x2& a01, f32x2& a23, const float4& v, float wk, float slope) {
+  if (ACT == gcl::kActPrelu) {
+    const float ws = wk * slope, w1 = wk - ws;
+    a01.x = fmaf(ws, v.x, a01.x); a01.y = fmaf(ws, v.y, a01.y);
+    a23.x = fmaf(ws, v.z, a23.x); a23.y = fmaf(ws, v.w, a23.y);
+    a01.x = fmaf(w1, relu1(v.x), a01.x); a01.y = fmaf(w1, relu1(v.y), a01.y);
+    a23.x = fmaf(w1, relu1(v.z), a23.x); a23.y = fmaf(w1, relu1(v.w), a23.y);
+  } else if (ACT == gcl::kActSilu) {
+    a01.x = fmaf(wk, gcl::silu_f(v.x), a01.x); a01.y = fmaf(wk, gcl::silu_f(v.y), a01.y);
+    a23.x = fmaf(wk, gcl::silu_f(v.z), a23.x); a23.y = fmaf(wk, gcl::silu_f(v.w), a23.y);
+  } else {
+    a01.x = fmaf(wk, v.x, a01.x); a01.y = fmaf(wk, v.y, a01.y);
+    a23.x = fmaf(wk, v.z, a23.x); a23.y = fmaf(wk, v.w, a23.y);
+  }
+}
+
+// SAFE: mask padded prefix slots with a select (GCL_GRAPH_MEAN: a padded slot points at the row itself, which is
+// NOT one of its neighbours there, so a non-finite value must not reach the sum through 0 * inf); GCN graphs
+// carry a self-loop in every row, padded slots have weight 0 and need no mask.
+template <int ACT, int EW, bool SAFE>
+__device__ __forceinline__ void gather_tile(float* __restrict__ At, int KP, float* __restrict__ Sink,
+                                            const float* __restrict__ Mt, RowBase rh, int64_t ldh,
+                                            int K, const int32_t* __restrict__ col, const float* __restrict__ w,
+                                            float slope) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane >> 4, l = lane & 15;
+  const int c0 = l * 4;
+  const bool cactive = c0 < K;
+  const int cc = c0 < K - 4 ? c0 : K - 4;  // lanes beyond K re-read the last 16 bytes of the row (never kept)
+  const int* rpl = reinterpret_cast<const int*>(Mt);
+  const int* ecl = rpl + kRpF;
+  const float* ewl = Mt + kRpF + 32 * gcl::kEll;
+  const unsigned ldb = (unsigned)ldh * 4u, ccb = (unsigned)cc * 4u;
+
+  auto rows_issue = [&](int p, float4 (&v)[EW]) {
+    const int i = p * 4 + sub;
+    int jj[8];
+    if (EW > 4) {
+      const int4 a = *reinterpret_cast<const int4*>(ecl + i * gcl::kEll), b = *reinterpret_cast<const int4*>(ecl + i * gcl::kEll + 4);
+      jj[0] = a.x; jj[1] = a.y; jj[2] = a.z; jj[3] = a.w; jj[4] = b.x; jj[5] = b.y; jj[6] = b.z; jj[7] = b.w;
+    } else {
+      const int4 a = *reinterpret_cast<const int4*>(ecl + i * gcl::kEll);
+      jj[0] = a.x; jj[1] = a.y; jj[2] = a.z; jj[3] = a.w; jj[4] = jj[5] = jj[6] = jj[7] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < EW; ++k) v[k] = row_ld4(rh, __umul24((unsigned)jj[k], ldb) + ccb);  // n, ld < 2^24
+  };
+  auto rows_sum = [&](int p, const float4 (&v)[EW]) {
+    const int i = p * 4 + sub;
+    float ww[8];
+    if (EW > 4) {
+      const float4 a = *reinterpret_cast<const float4*>(ewl + i * gcl::kEll), b = *reinterpret_cast<const float4*>(ewl + i * gcl::kEll + 4);
+      ww[0] = a.x; ww[1] = a.y; ww[2] = a.z; ww[3] = a.w; ww[4] = b.x; ww[5] = b.y; ww[6] = b.z; ww[7] = b.w;
+    } else {
+      const float4 a = *reinterpret_cast<const float4*>(ewl + i * gcl::kEll);
+      ww[0] = a.x; ww[1] = a.y; ww[2] = a.z; ww[3] = a.w; ww[4] = ww[5] = ww[6] = ww[7] = 0.f;
+    }
+    const int deg = rpl[i + 1] - rpl[i];
+    f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < EW; ++k) {
+      if (SAFE) {
+        float4 vk = v[k];
+        const bool in = k < deg;
+        vk.x = in ? vk.x : 0.f; vk.y = in ? vk.y : 0.f; vk.z = in ? vk.z : 0.f; vk.w = in ? vk.w : 0.f;
+        row_fma<ACT>(a01, a23, vk, ww[k], slope);
+      } else {
+        row_fma<ACT>(a01, a23, v[k], ww[k], slope);  // padded slots: weight 0 on a finite (own, self-looped) row
+      }
+    }
+    float2* d = reinterpret_cast<float2*>(cactive ? At + i * KP + c0 : Sink + l * 4);
+    d[0] = make_float2(a01.x, a01.y);
+    d[1] = make_float2(a23.x, a23.y);
+    return deg;
+  };
+
+  // three passes of row loads in flight per lane (ring of three register sets)
+  float4 va[EW], vb[EW], vc[EW];
+  int maxdeg = 0;
+  rows_issue(0, va);
+  rows_issue(1, vb);
+  rows_issue(2, vc);
+  maxdeg = max(maxdeg, rows_sum(0, va));
+  rows_issue(3, va);
+  maxdeg = max(maxdeg, rows_sum(1, vb));
+  rows_issue(4, vb);
+  maxdeg = max(maxdeg, rows_sum(2, vc));
+  rows_issue(5, vc);
+  maxdeg = max(maxdeg, rows_sum(3, va));
+  rows_issue(6, va);
+  maxdeg = max(maxdeg, rows_sum(4, vb));
+  rows_issue(7, vb);
+  maxdeg = max(maxdeg, rows_sum(5, vc));
+  maxdeg = max(maxdeg, rows_sum(6, va));
+  maxdeg = max(maxdeg, rows_sum(7, vb));
+
+  if (__any(maxdeg > EW)) {  // wave-uniform: some row of this tile has more edges than the prefix
+#pragma unroll 1
+    for (int p = 0; p < 8; ++p) {
+      const int i = p * 4 + sub;
+      const int st = rpl[i], end = rpl[i + 1];
+      if (!__any(end - st > EW)) continue;
+      float2* d = reinterpret_cast<float2*>(cactive ? At + i * KP + c0 : Sink + l * 4);
+      const float2 t0 = d[0], t1 = d[1];
+      f32x2 a01 = {t0.x, t0.y}, a23 = {t1.x, t1.y};
+      for (int e = st + EW; __any(e < end); e += 4) {  // 4 neighbour rows in flight per lane
+        int j[4];
+        float wk[4];
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = e + u < end;
+          j[u] = col[ok ? e + u : 0];  // (rows past n have st == E': never index with it)
+          wk[u] = ok ? w[ok ? e + u : 0] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = row_ld4(rh, __umul24((unsigned)j[u], ldb) + ccb);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float4 vu = v[u];
+          if (SAFE) {
+            const bool ok = e + u < end;
+            vu.x = ok ? vu.x : 0.f; vu.y = ok ? vu.y : 0.f; vu.z = ok ? vu.z : 0.f; vu.w = ok ? vu.w : 0.f;
+          }
+          row_fma<ACT>(a01, a23, vu, wk[u], slope);  // slots past the row's end: weight 0 on row col[0] (finite unless the input is not)
+        }
+      }
+      d[0] = make_float2(a01.x, a01.y);
+      d[1] = make_float2(a23.x, a23.y);
+    }
+  }
+}
+
+// acc[s] += At[32][K] x Wl[s*32..+31][K]^T  (fragment scheme of linear.hip: 8-byte reads, k pairs)
+template <int NS>
+__device__ __forceinline__ void mfma_tile(f32x16 (&acc)[NS], const float* __restrict__ At, const float* __restrict__ Wl,
+                                          int KP, int nq) {
+  const int lane = threadIdx.x & 63;
+  const float* ap = At + (lane & 31) * KP + 2 * (lane >> 5);
+  const float* bp = Wl + (lane & 31) * KP + 2 * (lane >> 5);
+  float2 a_c = *reinterpret_cast<const float2*>(ap);
+  float2 b_c[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) b_c[s] = *reinterpret_cast<const float2*>(bp + s * 32 * KP);
+  for (int q = 0; q < nq; ++q) {
+    const int qn = (q + 1 < nq) ? q + 1 : q;  // fragments of the next k pair are read before this pair's MFMAs issue
+    const float2 a_n = *reinterpret_cast<const float2*>(ap + qn * 4);
+    float2 b_n[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) b_n[s] = *reinterpret_cast<const float2*>(bp + s * 32 * KP + qn * 4);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c.x, b_c[s].x, acc[s], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c.y, b_c[s].y, acc[s], 0, 0, 0);
+    a_c = a_n;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) b_c[s] = b_n[s];
+  }
+}
+
+// Transpose the 32 x (NS*32) accumulator tile through the wave's LDS region Ot[32][NS*32] and write whole
+// 16-byte row segments:  Y[r0 + i][0 .. Nst) (rows >= nr and columns >= Nst dropped by the range check).
+template <int NS>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[NS], float* __restrict__ Ot, float* Ybase, int64_t ldy,
+                                           int nr, int Nst) {
+  constexpr int OS = NS * 32;          // floats per staged row
+  constexpr int LPO = OS / 4;          // lanes per row (8 or 16)
+  constexpr int RPP = 64 / LPO;        // rows per pass
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ot[d_row(r, lane) * OS + s * 32 + (lane & 31)] = acc[s][r];
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(Ybase, nr > 0 ? ((int64_t)(nr - 1) * ldy + Nst) * 4 : 0);
+  const int orow = lane / LPO, ocol = (lane % LPO) * 4;
+#pragma unroll
+  for (int p = 0; p < 32 / RPP; ++p) {
+    const int i = p * RPP + orow;
+    const float4 v = *reinterpret_cast<const float4*>(Ot + i * OS + ocol);
+    buf_st4(ry, (ocol < Nst) ? (unsigned)((i * ldy + ocol) * 4) : kOOB, v);
+  }
+}
+
+__device__ unsigned long long gl_stamps[8 * 4096];  // diagnostic builds only (make STAMPS=1)
+#ifdef GCL_STAMPS
+#define GCL_STAMP(slot)                                                                  \
+  do {                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    unsigned long long t_;                                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    stamp_acc[slot] += t_ - stamp_last;                                                  \
+    stamp_last = t_;                                                                     \
+  } while (0)
+#else
+#define GCL_STAMP(slot) do {} while (0)
+#endif
+
+// floats of one wave's LDS region
+__host__ __device__ constexpr int wave_region_f(int tile_f) { return tile_f + kSinkF + kMetaF; }
+
+template <int NS, int ACT, int EW, int NW, bool SAFE>
+__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void gcn_fwd_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ w,
+    const int32_t* __restrict__ ecol, const float* __restrict__ ew, const float* __restrict__ X, int64_t ldx,
+    int64_t bsx, const float* __restrict__ slope_p, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ Y, int64_t ldy, int64_t bsy, int32_t n, int32_t B, int32_t K, int32_t N, int32_t Nst,
+    int32_t nRT) {
+  extern __shared__ __align__(16) float smem[];
+  const int KP = K + 2;  // K % 4 == 0: even stride with KP/2 odd -> conflict-free 8-byte fragment reads
+  float* Wl = smem;      // [NS*32][KP]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int TILE_F = 32 * (KP > NS * 32 ? KP : NS * 32);  // the [32][KP] tile, reused as the [32][NS*32] output staging
+  float* At = smem + (size_t)NS * 32 * KP + (size_t)wave * wave_region_f(TILE_F);
+  float* Sink = At + TILE_F;
+  float* Mt = Sink + kSinkF;
+  stage_panel<false>(Wl, W, K, N, K, NS * 32, K, KP);
+  const float slope = (ACT == gcl::kActPrelu) ? *slope_p : 1.f;
+  float bj[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int j = s * 32 + (lane & 31);
+    bj[s] = (bias && j < N) ? bias[j] : 0.f;
+  }
+  __syncthreads();  // the only block barrier: from here on every wave works on its own LDS region
+
+  Sched sc;
+  sc.init(B, nRT, NW);
+  int b = sc.sample(), r0 = sc.row0();
+  if (sc.left <= 0) b = 0, r0 = 0;
+  TileMeta mt = meta_issue(rowptr, ecol, ew, r0, n);
+#ifdef GCL_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#endif
+  // Stagger: the waves run the same program, so without it they fall into lockstep - all twelve gather at once
+  // (the CU's load path is shared, each crawls), then all want the matrix pipe at once.  Wave groups 1 and 2
+  // start a third / two thirds of a tile period later; equal periods keep the offset.  (Speed only.)
+  {
+    const int grp = __builtin_amdgcn_readfirstlane(wave) >> 2;
+    for (int i = 0; i < grp * kStagger; ++i) __builtin_amdgcn_s_sleep(64);
+  }
+  while (sc.left > 0) {
+    GCL_STAMP(0);
+    meta_commit(Mt, mt);
+    sc.advance();
+    const int bn = sc.left > 0 ? sc.sample() : b, rn = sc.left > 0 ? sc.row0() : r0;
+    mt = meta_issue(rowptr, ecol, ew, rn, n);  // next tile's metadata: in flight during this tile
+    GCL_STAMP(1);
+    {
+      // prefix width of THIS tile: the widest row decides how many neighbour loads every lane issues
+      const int* rpl = reinterpret_cast<const int*>(Mt);
+      int dmax = rpl[(lane & 31) + 1] - rpl[lane & 31];
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) dmax = max(dmax, __shfl_xor(dmax, off, 64));
+      dmax = __builtin_amdgcn_readfirstlane(dmax);
+      const RowBase rh = sample_rows(X + (int64_t)b * bsx);
+      if (EW >= 8 && dmax > 4) gather_tile<ACT, 8, SAFE>(At, KP, Sink, Mt, rh, ldx, K, col, w, slope);
+      else if (EW >= 4 && dmax > 2) gather_tile<ACT, 4, SAFE>(At, KP, Sink, Mt, rh, ldx, K, col, w, slope);
+      else if (EW >= 2 && dmax > 1) gather_tile<ACT, 2, SAFE>(At, KP, Sink, Mt, rh, ldx, K, col, w, slope);
+      else gather_tile<ACT, 1, SAFE>(At, KP, Sink, Mt, rh, ldx, K, col, w, slope);
+    }
+    GCL_STAMP(2);
+    f32x16 acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][r] = bj[s];  // the bias rides in the accumulator's initial value
+    mfma_tile<NS>(acc, At, Wl, KP, K >> 2);
+#ifdef GCL_STAMPS
+    asm volatile("" ::"v"(acc[0][0]));
+#endif
+    GCL_STAMP(3);
+    store_tile<NS>(acc, At, Y + (int64_t)b * bsy + (int64_t)r0 * ldy, ldy, n - r0 < 32 ? n - r0 : 32, Nst);
+    GCL_STAMP(4);
+    b = bn;
+    r0 = rn;
+  }
+#ifdef GCL_STAMPS
+  if (lane == 0 && blockIdx.x < 4096 / NW) {
+    for (int i = 0; i < 8; ++i) gl_stamps[(blockIdx.x * NW + wave) * 8 + i] = stamp_acc[i];
+  }
+#endif
+}
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+}  // namespace
+
+#ifdef GCL_STAMPS
+// diagnostic builds only: per-wave cycle sums [wave][8] = {loop top, meta, gather, mfma, store, ...}
+extern "C" int gcl_debug_read_stamps(unsigned long long* host_out, int count) {
+  GCL_CHECK_HIP(hipDeviceSynchronize());
+  GCL_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(gl_stamps), sizeof(unsigned long long) * count));
+  return GCL_OK;
+}
+#endif
+
+extern "C" int gcl_gcn_layer_fwd(const gcl_graph_t* g, const float* x, int64_t ldx, int64_t bsx, int32_t act,
+                                 const float* slope, const float* W, const float* bias, float* y, int64_t ldy,
+                                 int64_t bsy, int32_t B, int32_t Fin, int32_t Fout, int32_t Fout_store,
+                                 gcl_stream_t stream) {
+  GCL_CHECK_ARG(g && x && W && y, "gcn_layer_fwd: null argument");
+  GCL_CHECK_ARG(g->kind == GCL_GRAPH_GCN || g->kind == GCL_GRAPH_MEAN, "gcn_layer_fwd: graph carries no edge weights");
+  GCL_CHECK_ARG(B > 0 && Fin >= 4 && Fin <= 64 && Fin % 4 == 0 && Fout >= 1 && Fout <= 64,
+                "gcn_layer_fwd: unsupported Fin=%d Fout=%d (Fin %% 4 == 0, both <= 64)", Fin, Fout);
+  GCL_CHECK_ARG(Fout_store >= Fout && Fout_store % 4 == 0 && Fout_store <= 64 && ldy >= Fout_store,
+                "gcn_layer_fwd: Fout_store=%d must be a multiple of 4 in [Fout, min(64, ldy)]", Fout_store);
+  GCL_CHECK_ARG(ldx >= Fin && ldx % 4 == 0 && bsx % 4 == 0 && gcl::aligned16(x), "gcn_layer_fwd: x rows must be 16-B aligned");
+  GCL_CHECK_ARG(ldy % 4 == 0 && bsy % 4 == 0 && gcl::aligned16(y), "gcn_layer_fwd: y rows must be 16-B aligned");
+  GCL_CHECK_ARG(g->n_heavy == 0, "gcn_layer_fwd: the graph has rows with more than %d in-edges", gcl::kHeavy);
+  GCL_CHECK_ARG(act == GCL_ACT_NONE || act == GCL_ACT_SILU || (act == GCL_ACT_PRELU && slope),
+                "gcn_layer_fwd: bad activation %d", act);
+  GCL_CHECK_ARG(x != y, "gcn_layer_fwd: in-place is not supported");
+  const int32_t n = g->n;
+  const int32_t nRT = (int32_t)gcl::cdiv(n, 32);
+  const int NS = Fout_store > 32 ? 2 : 1;
+  constexpr int NW = 12;
+  const int KP = Fin + 2;
+  const size_t lds = ((size_t)NS * 32 * KP + (size_t)NW * wave_region_f(32 * (KP > NS * 32 ? KP : NS * 32))) * sizeof(float);
+  GCL_CHECK_ARG((int64_t)n * ldx * 4 < (int64_t)1 << 31 && n < (1 << 24) && ldx * 4 < (1 << 24),
+                "gcn_layer_fwd: one sample of x must stay below 2 GiB (n, row bytes < 2^24)");
+  const int64_t tiles = (int64_t)B * nRT;
+  int64_t grid = gcl::kNumCU;
+  if (tiles < grid * NW) grid = gcl::cdiv(tiles, NW);
+  if (B >= gcl::kNumXCD) grid = gcl::cdiv(grid, gcl::kNumXCD) * gcl::kNumXCD;  // XCD-aware schedule needs a multiple of 8
+  const int ewidth = g->ell_cover;  // smallest prefix width that covers (almost) every row: the fix-up loop is the slow path
+  hipStream_t st = (hipStream_t)stream;
+#define GCL_GF4(NS_, ACT_, EW_)                                                                                      \
+  do {                                                                                                              \
+    auto kern = gcn_fwd_kernel<NS_, ACT_, EW_, NW, false>;                                                                  \
+    { static bool lds_set = false;                                                                                   \
+      if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, st, g->rowptr, g->col, g->w, g->ecol, g->ew, x, \
+                       ldx, bsx, slope, W, bias, y, ldy, bsy, n, B, Fin, Fout, Fout_store, nRT);                     \
+  } while (0)
+#define GCL_GF3(NS_, ACT_)                  \
+  do {                                      \
+    switch (ewidth) {                       \
+      case 8: GCL_GF4(NS_, ACT_, 8); break; \
+      case 4: GCL_GF4(NS_, ACT_, 4); break; \
+      default: GCL_GF4(NS_, ACT_, 2); break; \
+    }                                       \
+  } while (0)
+#define GCL_GF2(NS_)                                         \
+  do {                                                       \
+    if (act == GCL_ACT_PRELU) GCL_GF3(NS_, gcl::kActPrelu);  \
+    else if (act == GCL_ACT_SILU) GCL_GF3(NS_, gcl::kActSilu); \
+    else GCL_GF3(NS_, gcl::kActNone);                        \
+  } while (0)
+  if (g->kind == GCL_GRAPH_MEAN) {  // no self-loops: masked (SAFE) variant, activation-free, widest prefix
+    GCL_CHECK_ARG(act == GCL_ACT_NONE, "gcn_layer_fwd: mean-aggregation graphs take no activation");
+    if (NS == 2) {
+      auto kern = gcn_fwd_kernel<2, gcl::kActNone, 8, NW, true>;
+      GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, st, g->rowptr, g->col, g->w, g->ecol, g->ew, x, ldx,
+                         bsx, slope, W, bias, y, ldy, bsy, n, B, Fin, Fout, Fout_store, nRT);
+    } else {
+      auto kern = gcn_fwd_kernel<1, gcl::kActNone, 8, NW, true>;
+      GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, st, g->rowptr, g->col, g->w, g->ecol, g->ew, x, ldx,
+                         bsx, slope, W, bias, y, ldy, bsy, n, B, Fin, Fout, Fout_store, nRT);
+    }
+  } else if (NS == 2) GCL_GF2(2);
+  else GCL_GF2(1);
+#undef GCL_GF2
+#undef GCL_GF3
+#undef GCL_GF4
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}

@@ -222,6 +222,16 @@ extern "C" int gcl_graph_create(const int64_t* ei, int64_t E, int32_t n, int32_t
   std::vector<float> ewv, tewv;
   g->ell_width = build_ell(rowptr, col, w, ec, ewv);
   g->tell_width = build_ell(trowptr, tcol, tw, tec, tewv);
+  auto cover = [&](const std::vector<int32_t>& rp) {
+    for (int cand : {2, 4}) {
+      int64_t over = 0;
+      for (int32_t i = 0; i < n; ++i) over += (rp[i + 1] - rp[i]) > cand;
+      if (over * 50 <= n) return cand;
+    }
+    return 8;
+  };
+  g->ell_cover = cover(rowptr);
+  g->tell_cover = cover(trowptr);
   if (!rc) rc = upload(&g->ecol, ec.data(), ec.size());
   if (!rc) rc = upload(&g->ew, ewv.data(), ewv.size());
   if (!rc) rc = upload(&g->tecol, tec.data(), tec.size());

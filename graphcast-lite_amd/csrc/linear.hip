@@ -60,6 +60,9 @@ __device__ __forceinline__ int64_t win_bytes(int64_t nrows, int64_t ld, int F) {
 
 #include "gemm_tile.h"
 
+// A/B switch while tuning (kernel argument `abl` bit 8 = keep the per-tile block barriers of round 1)
+#define gcl_lin_sync() ((abl & 8) != 0)
+
 // ---------------------------------------------------------------------------------------------
 // Y[r, j] = sum_k act(X[r,k]) * Wl[j,k]   with Wl[j,k] = TRANS ? W[k*ldw + j] : W[j*ldw + k]
 //   EPI_BIAS: + bias[j]
@@ -99,11 +102,25 @@ __global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel
   const int NT = blockDim.x;
   const int TM = (NT >> 6) * 32;  // rows per tile
 
-  for (int idx = tid; idx < NS * 32 * KE; idx += NT) {
-    const int j = idx / KE, k = idx - j * KE;
-    float v = 0.f;
-    if (j < N && k < K) v = trans ? W[(int64_t)k * ldw + j] : W[(int64_t)j * ldw + k];
-    Wl[j * KP + k] = v;
+  // weight panel: 8 independent loads in flight per thread before the first LDS write (a load -> wait ->
+  // write loop costs one L2 round trip per element and that latency is paid by every block's first tile)
+  for (int base = 0; base < NS * 32 * KE; base += NT * 8) {
+    float wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * NT + tid;
+      const int j = idx / KE, k = idx - j * KE;
+      const bool ok = (idx < NS * 32 * KE) && (j < N) && (k < K);
+      const float* src = ok ? (trans ? W + (int64_t)k * ldw + j : W + (int64_t)j * ldw + k)
+                            : reinterpret_cast<const float*>(gcl_zero4);
+      wv[u] = *src;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * NT + tid;
+      const int j = idx / KE, k = idx - j * KE;
+      if (idx < NS * 32 * KE) Wl[j * KP + k] = wv[u];
+    }
   }
   // akind: activation of X (EPI_BIAS) or of Z (EPI_DX); PReLU reads its slope from in_slope / z_slope
   const float slope = in_slope ? *in_slope : 1.f;
@@ -142,7 +159,17 @@ __global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel
       }
     }
   };
+  // Activation while committing: PReLU and "none" share one branch-free form (x > 0 ? x : x * a with a = 1 for
+  // none: exact); SiLU is a block-uniform variant of the whole commit, not a branch per element.
+  const float pa = (act && !silu) ? slope : 1.f;
   auto commit = [&]() {
+    if (act && silu) {
+#pragma unroll
+      for (int q = 0; q < (VEC ? NIT * 4 : NIT); ++q) pre[q] = gcl::silu_f(pre[q]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < (VEC ? NIT * 4 : NIT); ++q) pre[q] = pre[q] > 0.f ? pre[q] : pre[q] * pa;
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int r = (it / IPR) * RPI + rsub;
@@ -150,16 +177,11 @@ __global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel
       if (VEC) {
         if (c * 4 < KE) {
           float2* d = reinterpret_cast<float2*>(Xw + r * KP + c * 4);
-          float v0 = pre[4 * it], v1 = pre[4 * it + 1], v2 = pre[4 * it + 2], v3 = pre[4 * it + 3];
-          if (act) {
-            v0 = gcl::act_f(v0, slope, akind); v1 = gcl::act_f(v1, slope, akind);
-            v2 = gcl::act_f(v2, slope, akind); v3 = gcl::act_f(v3, slope, akind);
-          }
-          d[0] = make_float2(v0, v1);
-          d[1] = make_float2(v2, v3);
+          d[0] = make_float2(pre[4 * it], pre[4 * it + 1]);
+          d[1] = make_float2(pre[4 * it + 2], pre[4 * it + 3]);
         }
       } else {
-        if (c < KE) Xw[r * KP + c] = act ? gcl::act_f(pre[it], slope, akind) : pre[it];  // zero beyond K
+        if (c < KE) Xw[r * KP + c] = pre[it];  // zero beyond K
       }
     }
   };
@@ -174,10 +196,15 @@ __global__ __launch_bounds__(256, lin_min_waves(NS, KT)) void linear_mfma_kernel
   const bool has_z = (EPI == EPI_DX) && (Z != nullptr);
 
   issue(blockIdx.x);
+  __syncthreads();  // the weight panel is staged; from here on every wave only touches ITS rows of Xl
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    __syncthreads();  // previous tile's fragment reads are done (also orders the Wl staging)
+    // No block barrier inside the loop: a wave's staging rows are private to it and LDS operations of one
+    // wave complete in order, so the waves of a block (and of the other blocks on the CU) drift apart and one
+    // wave's MFMA chain overlaps the others' loads, LDS commits and stores.
+    if (!gcl_lin_sync()) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    else __syncthreads();
     commit();
-    __syncthreads();
+    if (gcl_lin_sync()) __syncthreads();
     issue(t + gridDim.x);  // unconditional: an empty window past the last tile returns zeros
 
     const int64_t r0 = t * TM;

@@ -138,31 +138,31 @@ class GCNStackFn(torch.autograd.Function):
             W, b = params[2 * k].detach(), params[2 * k + 1].detach()
             Fout = W.shape[0]
             ldh = (Fout + 3) // 4 * 4  # padded scratch so the gather can use 16-B loads
+            act_k, slope_k = (akind, slope_t) if k > 0 else (hip.ACT_NONE, None)
+            if hip.gcn_layer_fusable(graph, cur, W.shape[1], Fout):
+                # ONE kernel (csrc/gcn_layer.hip): gather-aggregate the activated input rows, then the dense
+                # transform; an output width that is not a multiple of 4 (33 / 19 variables) is stored ldh wide
+                # with zero padding columns, so the layer and its backward stay on 16-byte rows
+                p = hip.gcn_layer_fwd(graph, cur, act_k, slope_k, W, b)
+                if k == L - 1 and ldh != Fout and not has_ln:
+                    pad_last = (ldh, Fout, None)
+                elif ldh != Fout:
+                    p = p.contiguous()  # an odd width that feeds another layer / the LayerNorm: dense rows
+                ps.append(p)
+                cur = p
+                continue
             if k == L - 1 and ldh != Fout and not has_ln:
-                # An output width that is not a multiple of 4 (33 or 19 variables) would push this layer and
-                # its whole backward onto scalar memory accesses.  Run it ldh wide instead, with zero
-                # weight rows / bias entries for the extra columns (they stay exactly 0), and return
-                # the first Fout columns as a view.
+                # two-kernel path of the same padded layer: zero weight rows / bias entries for the extra columns
                 Wp = torch.nn.functional.pad(W, (0, 0, 0, ldh - Fout))
                 bp = torch.nn.functional.pad(b, (0, ldh - Fout))
-                if hip.gcn_layer_fusable(graph, cur, W.shape[1], ldh):
-                    p = hip.gcn_layer_fwd(graph, cur, akind if k > 0 else hip.ACT_NONE, slope_t if k > 0 else None, Wp, bp)
-                else:
-                    h = hip.linear_fwd(cur.reshape(B * n, -1), Wp, None, slope_t if k > 0 else None,
-                                       act=akind if k > 0 else hip.ACT_NONE)
-                    p = hip.aggregate(graph, h.view(B, n, ldh), bp)
+                h = hip.linear_fwd(cur.reshape(B * n, -1), Wp, None, slope_k, act=act_k)
+                p = hip.aggregate(graph, h.view(B, n, ldh), bp)
                 ps.append(p)
                 cur = p[..., :Fout]
                 pad_last = (ldh, Fout, Wp)
                 continue
-            if hip.gcn_layer_fusable(graph, cur, W.shape[1], Fout):
-                # one kernel: gather-aggregate the activated input rows, then the dense transform
-                p = hip.gcn_layer_fwd(graph, cur, akind if k > 0 else hip.ACT_NONE, slope_t if k > 0 else None, W, b)
-                ps.append(p)
-                cur = p
-                continue
-            h = hip.linear_fwd(cur.view(B * n, -1), W, None, slope_t if k > 0 else None, ld_out=ldh,
-                               act=akind if k > 0 else hip.ACT_NONE)
+            h = hip.linear_fwd(cur.reshape(B * n, -1) if not cur.is_contiguous() else cur.view(B * n, -1), W, None, slope_k,
+                               ld_out=ldh, act=act_k)
             h3 = torch.as_strided(h, (B, n, Fout), (n * ldh, ldh, 1))
             p = hip.aggregate(graph, h3, b)
             ps.append(p)
@@ -199,6 +199,9 @@ class GCNStackFn(torch.autograd.Function):
         pad = ctx.pad_last
         if pad is not None:  # widen the incoming gradient to the padded width (extra columns 0)
             Fp, Fo, Wp = pad
+            if Wp is None:  # (the fused forward needed no padded copy of the weight)
+                Wp = torch.nn.functional.pad(params[2 * (L - 1)].detach(), (0, 0, 0, Fp - Fo))
+                pad = (Fp, Fo, Wp)
             dp = torch.nn.functional.pad(dy3, (0, Fp - Fo))  # one pass: copy + zero columns
         bi_last = 2 * L - 1
         if G.dst[bi_last] is not None:  # bias of the last conv: its dp comes from outside this stack

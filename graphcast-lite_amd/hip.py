@@ -68,7 +68,7 @@ _SIGNATURES = {
                                    _vp, C.c_size_t, _vp]),
     "gcl_dense_bwd_dw": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp,
                                    C.c_size_t, _vp]),
-    "gcl_gcn_layer_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "gcl_gcn_layer_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "gcl_segment_reduce": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "gcl_edge_combine": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i32, _i64, _i32, _vp]),
     "gcl_act_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
@@ -607,22 +607,25 @@ def window_pack(series, t0, mean, std, C: int, obs: int, pred: int):
 
 
 def gcn_layer_fusable(graph: Graph, x3, Fin: int, Fout: int) -> bool:
-    """Should this layer go through gcl_gcn_layer_fwd?  Opt-in (GCL_FUSED_GCN=1): on MI355X the one-kernel
-    layer measured SLOWER than linear_fwd + aggregate (4.46 vs 4.01 ms per baseline step):
-    its LDS tile + weight panel cap the waves per CU below what the gather wants."""
+    """Does this GCNConv layer fit the one-kernel path (csrc/gcn_layer.hip)?  GCL_FUSED_GCN=0 forces the
+    two-kernel path (linear + aggregate) for A/B measurements."""
     import os
-    if os.environ.get("GCL_FUSED_GCN", "0") in ("0", ""):
+    if os.environ.get("GCL_FUSED_GCN", "1") in ("0",):
         return False
-    return (Fin % 4 == 0 and 4 <= Fin <= 64 and 1 <= Fout <= 64 and graph.max_in_degree <= 64 and graph.kind == GRAPH_GCN
+    return (Fin % 4 == 0 and 4 <= Fin <= 64 and 1 <= Fout <= 64 and graph.max_in_degree <= 64 and graph.kind in (GRAPH_GCN, GRAPH_MEAN)
             and x3.stride(2) == 1 and x3.stride(1) % 4 == 0 and x3.stride(0) % 4 == 0 and x3.data_ptr() % 16 == 0)
 
 
-def gcn_layer_fwd(graph: Graph, x3, act, slope, W, bias):
-    """y = (A_hat act(x)) W^T + bias for x3 [B, n, Fin] -> [B, n, Fout] (one kernel)."""
+def gcn_layer_fwd(graph: Graph, x3, act, slope, W, bias, out=None):
+    """y = (A_hat act(x)) W^T + bias for x3 [B, n, Fin] -> [B, n, Fout] (one kernel).  The result is a view of
+    a [B, n, roundup(Fout, 4)] buffer whose padding columns are zero."""
     B, n, Fin = x3.shape
     assert n == graph.n
     Fout = W.shape[0]
-    y = torch.empty(B, n, Fout, dtype=torch.float32, device=x3.device)
+    Fst = (Fout + 3) // 4 * 4
+    if out is None:
+        out = torch.empty(B, n, Fst, dtype=torch.float32, device=x3.device)
+    assert out.shape[2] >= Fst or out.stride(1) >= Fst
     _check(lib().gcl_gcn_layer_fwd(graph.handle, _p(x3), x3.stride(1), x3.stride(0), int(act), _p(slope), _p(W.contiguous()),
-                                   _p(bias), _p(y), Fout, n * Fout, B, Fin, Fout, _stream()))
-    return y
+                                   _p(bias), _p(out), out.stride(1), out.stride(0), B, Fin, Fout, Fst, _stream()))
+    return out[..., :Fout]

@@ -264,11 +264,15 @@ int gcl_copy_rows(const float* src, int64_t lds, int64_t bss, float* dst, int64_
 /* One whole GCNConv layer forward (src/models.py:419) in one kernel, aggregate-first:
  *   y[b,i,:] = (sum_{e in row i} w_e act(x[b, col_e, :])) W^T + bias
  * - the same value as gcl_linear_fwd followed by gcl_aggregate up to fp32 rounding (the aggregation is
- * linear), without the intermediate h in memory.  Fin % 4 == 0, Fin, Fout <= 64, x rows 16-B aligned,
- * graphs without heavy rows (in-degree <= 64); other shapes use the two calls. */
+ * linear), without the intermediate h in memory (csrc/gcn_layer.hip: wave-independent gather -> LDS tile ->
+ * exact-fp32 MFMA -> 16-byte row stores).  Columns [Fout, Fout_store) of y are written as zeros
+ * (Fout_store = Fout rounded up to a multiple of 4 keeps 33- / 19-wide outputs on 16-byte rows).
+ * Needs Fin % 4 == 0, Fin, Fout_store <= 64, 16-B aligned rows of x and y, and a graph without heavy rows
+ * (in-degree <= 64); other shapes use gcl_linear_fwd + gcl_aggregate. */
 int gcl_gcn_layer_fwd(const gcl_graph_t* g, const float* x, int64_t ldx, int64_t bsx, int32_t act,
                       const float* slope, const float* W /*[Fout,Fin]*/, const float* bias, float* y,
-                      int64_t ldy, int64_t bsy, int32_t B, int32_t Fin, int32_t Fout, gcl_stream_t stream);
+                      int64_t ldy, int64_t bsy, int32_t B, int32_t Fin, int32_t Fout, int32_t Fout_store,
+                      gcl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Edge-wise glue of the InteractionNet processor (src/models.py:206-236); csrc/interaction.hip.

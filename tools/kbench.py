@@ -43,7 +43,9 @@ def main():
     ap.add_argument("--config", default="baseline")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--only", default="", help="comma list of: copy,linear,agg,norm,misc (default all)")
+    ap.add_argument("--only", default="", help="comma list of: copy,linear,agg,gcn,norm,misc (default all)")
+    ap.add_argument("--rcb", type=int, default=0, help="renumber the mesh nodes by recursive coordinate bisection "
+                    "with leaves of this many nodes (locality experiment; 0 = reference order)")
     args = ap.parse_args()
     name = "wb2_512x256_19f_ar" if args.config.startswith("wb2") else args.config
     dev = torch.device("cuda:0")
@@ -58,7 +60,7 @@ def main():
     print(f"# {name}: B={B} G={G} M={M} n={n} F={F}")
     g = torch.Generator().manual_seed(0)
     rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
-    only = set(args.only.split(",")) if args.only else {"copy", "linear", "agg", "norm", "misc"}
+    only = set(args.only.split(",")) if args.only else {"copy", "linear", "agg", "gcn", "norm", "misc"}
 
     # stream copy ceiling
     if "copy" in only:
@@ -84,6 +86,24 @@ def main():
         row(f"linear_bwd_all {tag} (dx+dW+db+colsum)", us, mn, 4 * rows * (2 * K + N), 4 * rows * K * N)
 
     from graphcast_lite_amd.models import _graphs
+    if args.rcb:
+        v = np.asarray(m._finest_mesh.vertices)
+
+        def rcb(ids):
+            if len(ids) <= args.rcb:
+                return [ids]
+            pts = v[ids]
+            ax = int(np.argmax(pts.max(0) - pts.min(0)))
+            o = ids[np.argsort(pts[:, ax], kind="stable")]
+            h = (len(o) // 2 + args.rcb - 1) // args.rcb * args.rcb
+            h = min(max(h, args.rcb), len(o) - 1)
+            return rcb(o[:h]) + rcb(o[h:])
+
+        order = np.concatenate(rcb(np.arange(M)))
+        pos = np.empty(M, dtype=np.int64)
+        pos[order] = np.arange(M)
+        m.processing_graph = torch.from_numpy(pos)[m.processing_graph.cpu()].to(dev)
+        print(f"# mesh nodes renumbered by RCB (leaf {args.rcb})")
     for ei, nn_, tag in () if "agg" not in only else ((m.processing_graph, M, "mesh E_M"), (m.encoding_graph, n, "enc E_G2M"), (m.decoding_graph, n, "dec E_M2G")):
         gr = _graphs.get(ei, nn_, hip.GRAPH_GCN)
         h, bias = rnd(B, nn_, F), rnd(F)
@@ -93,6 +113,16 @@ def main():
         row(f"aggregate fwd {tag} n={nn_} E'={gr.e} F={F}", us, mn, B * per, 2 * B * gr.e * F)
         us, mn = timeit(lambda: hip.aggregate(gr, h, None, transpose=True, out=out), args.iters)
         row(f"aggregate bwd {tag} (transpose)", us, mn, B * per, 2 * B * gr.e * F)
+
+    # one-kernel GCNConv layer (aggregate-first): the same per-layer algorithmic bytes as the aggregation
+    for ei, nn_, tag in () if "gcn" not in only else ((m.processing_graph, M, "mesh E_M"), (m.encoding_graph, n, "enc E_G2M"), (m.decoding_graph, n, "dec E_M2G")):
+        gr = _graphs.get(ei, nn_, hip.GRAPH_GCN)
+        x, W, bias = rnd(B, nn_, F), rnd(F, F) * 0.1, rnd(F)
+        out = torch.empty(B, nn_, F, device=dev)
+        per = 4 * nn_ * 2 * F + 4 * gr.e + 4 * (nn_ + 1) + 4 * nn_
+        for act, an in ((hip.ACT_NONE, "none"), (hip.ACT_PRELU, "prelu")):
+            us, mn = timeit(lambda: hip.gcn_layer_fwd(gr, x, act, slope if act else None, W, bias, out=out), args.iters)
+            row(f"gcn_layer_fwd {tag} act={an} F={F}", us, mn, B * per, 2 * B * nn_ * F * F + 2 * B * gr.e * F)
 
     if "norm" not in only:
         return
