@@ -32,6 +32,31 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (MI355X_MICROARCH.md): 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
 
 
+class LaunchProbe:
+    """HIP events (recorded on the launch stream) around the launches of the roofline kernels; installed as
+    `hip.PROBE` only while the roofline leg of the benchmark runs."""
+
+    def __init__(self, match):
+        self.match, self.events = match, {}
+
+    def begin(self, kind, **info):
+        key = self.match(kind, info)
+        if key is None:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return key, e0, e1
+
+    def end(self, tok):
+        key, e0, e1 = tok
+        e1.record()
+        self.events.setdefault(key, []).append((e0, e1))
+
+    def mean_ms(self, key):
+        ev = self.events.get(key, [])
+        return (sum(a.elapsed_time(b) for a, b in ev) / len(ev), len(ev)) if ev else (None, 0)
+
+
 def build_model(name, device, seed=42):
     from graphcast_lite_amd.experiments import GRID, experiment
     from graphcast_lite_amd.models import WeatherPrediction
@@ -270,16 +295,24 @@ def main():
 
     def arm_profile():
         # HIP events around the roofline kernel's launches (recorded on the launch stream)
-        if is_gcn:
-            hip.AGG_PROFILE = {"graph": models._graphs.get(model.processing_graph, M, hip.GRAPH_GCN), "events": []}
-        if is_inet:  # the edge-MLP contractions [B*E, D] x [D, D]: 2 per message-passing step, forward
-            hip.DENSE_PROFILE = {"rows": B * int(model.processing_graph.shape[1]),
-                                 "Fin": cfg.pipeline.processor.gcn.output_dim,
-                                 "Fout": cfg.pipeline.processor.gcn.output_dim, "events": []}
+        pg = models._graphs.get(model.processing_graph, M, hip.GRAPH_GCN) if is_gcn else None
+        D = cfg.pipeline.processor.gcn.output_dim
+        E = int(model.processing_graph.shape[1])
 
+        def match(kind, info):
+            if is_gcn and kind in ("aggregate", "gcn_layer_fwd") and info["graph"] is pg:
+                return kind + ("_T" if info.get("transpose") else "")
+            if is_inet and kind == "dense_fwd" and (info["rows"], info["Fin"], info["Fout"]) == (B * E, D, D):
+                return "edge_mlp"  # the edge-MLP contractions [B*E, D] x [D, D]: 2 per message-passing step, forward
+            return None
+
+        hip.PROBE = LaunchProbe(match)
+        return hip.PROBE
+
+    probe = None
     replayed = step.graph_active
     if not replayed:
-        arm_profile()  # eager timed region: the events sit inside it
+        probe = arm_profile()  # eager timed region: the events sit inside it
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -300,7 +333,7 @@ def main():
         # Kernels replayed from a hipGraph cannot be bracketed by timing events on ROCm, so the
         # roofline kernel is timed on a few eager steps of the SAME step function right after the
         # timed region (same buffers, same launches; the rocprofv3 trace in profiles/ covers both).
-        arm_profile()
+        probe = arm_profile()
         roof_steps = max(3, min(args.steps, 10))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -340,32 +373,43 @@ def main():
         torch.cuda.synchronize()
         return 2.0 * a.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
-    if is_gcn and hip.AGG_PROFILE["events"]:
-        ev = hip.AGG_PROFILE["events"]
-        ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    hip.PROBE = None
+    if is_gcn and probe is not None:
         F = cfg.pipeline.processor.gcn.output_dim
-        pg = hip.AGG_PROFILE["graph"]
+        pg = models._graphs.get(model.processing_graph, M, hip.GRAPH_GCN)
         Ep = pg.e
-        per_sample = 4 * M * (F + F) + 4 * Ep + 4 * (M + 1) + 4 * M
-        achieved = B * per_sample / (ms * 1e-3) / 1e9
+        per_sample = 4 * M * (F + F) + 4 * Ep + 4 * (M + 1) + 4 * M  # one mesh GCNConv layer, per sample
         copy_gbs = copy_ceiling_gbs()
-        gather_counted = B * (per_sample + 4 * Ep * F) / (ms * 1e-3) / 1e9  # what an edge-wise gather would move
-        roof = {"bound": "hbm", "kernel": "agg_kernel (mesh GCNConv aggregate, forward)", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "bytes_per_launch": B * per_sample, "avg_launch_us": ms * 1e3, "launches_timed": len(ev),
-                "copy_ceiling_gbs": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,
-                "achieved_gather_counted_gbs": gather_counted}
-    hip.AGG_PROFILE = None
-    if is_inet and hip.DENSE_PROFILE["events"]:
-        ev = hip.DENSE_PROFILE["events"]
-        ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+        def line(key, what):
+            ms, cnt = probe.mean_ms(key)
+            if ms is None:
+                return None
+            ach = B * per_sample / (ms * 1e-3) / 1e9
+            return {"kernel": what, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "avg_launch_us": ms * 1e3, "launches_timed": cnt, "frac_of_copy_ceiling": ach / copy_gbs}
+
+        # the scatter-gather kernel of the mesh processor: forward launches when the layer runs as linear +
+        # aggregate, transposed (backward) launches otherwise - the mesh graph is symmetric, both move the same
+        # algorithmic bytes through the same agg_kernel instantiation
+        agg = line("aggregate", "agg_kernel (mesh GCNConv aggregate, forward)") or \
+            line("aggregate_T", "agg_kernel (mesh GCNConv aggregate, transposed CSR = backward of the layer)")
+        fused = line("gcn_layer_fwd", "gcn_fwd_kernel (whole mesh GCNConv layer forward in one launch: gather + dense)")
+        roof = agg or fused
+        if roof is not None:
+            roof = dict(roof, bound="hbm", traffic=traffic, bytes_per_launch=B * per_sample, copy_ceiling_gbs=copy_gbs,
+                        achieved_gather_counted_gbs=B * (per_sample + 4 * Ep * F) / (roof["avg_launch_us"] * 1e-6) / 1e9)
+            if fused is not None and roof is not fused:
+                # same algorithmic bytes (X in, Y out, CSR): the one-kernel layer replaces linear + aggregate
+                roof["gcn_layer_one_kernel"] = fused
+    if is_inet and probe is not None and probe.events.get("edge_mlp"):
+        ms, cnt = probe.mean_ms("edge_mlp")
         D, E = cfg.pipeline.processor.gcn.output_dim, int(model.processing_graph.shape[1])
         flops = 2.0 * B * E * D * D
         achieved = flops / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "gemm_tile_kernel (InteractionNet edge MLP, [B*E, D] x [D, D], forward)",
                 "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                "traffic": None, "flops_per_launch": flops, "avg_launch_us": ms * 1e3, "launches_timed": len(ev)}
-    hip.DENSE_PROFILE = None
+                "traffic": None, "flops_per_launch": flops, "avg_launch_us": ms * 1e3, "launches_timed": cnt}
 
     if rank == 0:
         out = {

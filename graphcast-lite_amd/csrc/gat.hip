@@ -28,7 +28,9 @@ __global__ __launch_bounds__(256) void gat_scores_kernel(const float* __restrict
                                                          const float* __restrict__ att_s,
                                                          const float* __restrict__ att_d, float* __restrict__ a_s,
                                                          float* __restrict__ a_d, int32_t n, int32_t B, int32_t H,
-                                                         int32_t C) {
+                                                         int32_t C, int32_t Hs, int32_t h0) {
+  // H = heads of THIS launch (a chunk of the layer's heads when H_total * C > 256 or H_total is not a power of
+  // two); per-head arrays are indexed [.., Hs] at head offset h0 (Hs = H_total, h0 = first head of the chunk)
   constexpr int RPW = 64 / LPR, RPB = RPW * 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
@@ -56,8 +58,8 @@ __global__ __launch_bounds__(256) void gat_scores_kernel(const float* __restrict
     }
     if (cact && (l % lph) == 0) {
       const int h = c0 / C;
-      a_s[r * H + h] = ps;
-      a_d[r * H + h] = pd;
+      a_s[r * Hs + h0 + h] = ps;
+      a_d[r * Hs + h0 + h] = pd;
     }
   }
 }
@@ -70,7 +72,8 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict_
                                                       const float* __restrict__ a_d, const float* __restrict__ bias,
                                                       float* __restrict__ alpha, float* __restrict__ Y, int64_t ldy,
                                                       int64_t bsy, int32_t n, int64_t Ep, int32_t B, int32_t H,
-                                                      int32_t C, int32_t nRB, int32_t xcd_map) {
+                                                      int32_t C, int32_t nRB, int32_t xcd_map, int32_t Hs, int32_t h0,
+                                                      int32_t Htot, int32_t yacc) {
   constexpr int RPW = 64 / LPR, RPB = RPW * 4;
   constexpr int EL = LPR < gcl::kEll ? LPR : gcl::kEll;
   const int bid = blockIdx.x;
@@ -95,11 +98,11 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict_
   const int h = cc / C;
   const int rc = row < n ? row : n - 1;
   const float* __restrict__ Hb = Hf + (int64_t)b * bsh;
-  const float* __restrict__ as_b = a_s + (int64_t)b * n * H;
+  const float* __restrict__ as_b = a_s + (int64_t)b * n * Hs + h0;
   // metadata: one round trip (the ELL prefix does not depend on rowptr)
   const int start = rowptr[rc], end = rowptr[rc + 1];
   const int cj = ecol[(int64_t)rc * gcl::kEll + (l & (EL - 1))];
-  const float ad = a_d[((int64_t)b * n + rc) * H + h];
+  const float ad = a_d[((int64_t)b * n + rc) * Hs + h0 + h];
   const int deg = end - start;
   const bool leader = active && (l % lph) == 0;
   float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict_
       const int hl = l % lph, hbase = gbase + (l / lph) * lph;
       const bool mine = hl < EL && hl < deg;
       const int jm = __shfl(cj, gbase + (hl & (EL - 1)), 64);
-      float e = mine ? leaky(as_b[(int64_t)jm * H + h] + ad) : -INFINITY;
+      float e = mine ? leaky(as_b[(int64_t)jm * Hs + h] + ad) : -INFINITY;
       float m = e;
 #pragma unroll
       for (int off = EL >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));  // lanes 0..EL-1 of the head
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict_
       for (int off = EL >> 1; off > 0; off >>= 1) den += __shfl_xor(den, off, 64);
       den = __shfl(den, hbase, 64);
       const float almine = ex * (1.f / (den + 1e-16f));
-      if (alpha && mine && active) alpha[((int64_t)b * Ep + start + hl) * H + h] = almine;
+      if (alpha && mine && active) alpha[((int64_t)b * Ep + start + hl) * Hs + h0 + h] = almine;
 #pragma unroll
       for (int k = 0; k < EL; ++k) {
         const float al = __shfl(almine, hbase + k, 64);
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict_
       }
     } else {
 #pragma unroll
-    for (int k = 0; k < EL; ++k) sc[k] = as_b[(int64_t)jj[k] * H + h];
+    for (int k = 0; k < EL; ++k) sc[k] = as_b[(int64_t)jj[k] * Hs + h];
     float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < EL; ++k) {
@@ -166,21 +169,21 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict_
       a1 += in ? al * v[k].y : 0.f;
       a2 += in ? al * v[k].z : 0.f;
       a3 += in ? al * v[k].w : 0.f;
-      if (leader && alpha && in) alpha[((int64_t)b * Ep + start + k) * H + h] = al;
+      if (leader && alpha && in) alpha[((int64_t)b * Ep + start + k) * Hs + h0 + h] = al;
     }
     }
   } else {
     float m = -INFINITY;
-    for (int e = start; e < end; ++e) m = fmaxf(m, leaky(as_b[(int64_t)col[e] * H + h] + ad));
+    for (int e = start; e < end; ++e) m = fmaxf(m, leaky(as_b[(int64_t)col[e] * Hs + h] + ad));
     float den = 0.f;
-    for (int e = start; e < end; ++e) den += expf(leaky(as_b[(int64_t)col[e] * H + h] + ad) - m);
+    for (int e = start; e < end; ++e) den += expf(leaky(as_b[(int64_t)col[e] * Hs + h] + ad) - m);
     const float inv = 1.f / (den + 1e-16f);
     for (int e = start; e < end; ++e) {
       const int j = col[e];
-      const float al = expf(leaky(as_b[(int64_t)j * H + h] + ad) - m) * inv;
+      const float al = expf(leaky(as_b[(int64_t)j * Hs + h] + ad) - m) * inv;
       const float4 v = *reinterpret_cast<const float4*>(Hb + (int64_t)j * ldh + cc);
       a0 += al * v.x; a1 += al * v.y; a2 += al * v.z; a3 += al * v.w;
-      if (leader && alpha) alpha[((int64_t)b * Ep + e) * H + h] = al;
+      if (leader && alpha) alpha[((int64_t)b * Ep + e) * Hs + h0 + h] = al;
     }
   }
   // mean over heads: lanes holding the same channel of different heads are lph apart
@@ -189,10 +192,14 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict_
     a2 += __shfl_xor(a2, off, 64); a3 += __shfl_xor(a3, off, 64);
   }
   if (active && h == 0) {
-    const float s = 1.f / (float)H;
+    const float s = 1.f / (float)Htot;  // mean over ALL heads of the layer; later chunks add onto the first one's result
     float* yp = Y + (int64_t)b * bsy + (int64_t)row * ldy + c0;
     float o0 = a0 * s, o1 = a1 * s, o2 = a2 * s, o3 = a3 * s;
     if (bias) { o0 += bias[c0]; o1 += bias[c0 + 1]; o2 += bias[c0 + 2]; o3 += bias[c0 + 3]; }
+    if (yacc) {
+      const float4 old = *reinterpret_cast<const float4*>(yp);
+      o0 += old.x; o1 += old.y; o2 += old.z; o3 += old.w;
+    }
     *reinterpret_cast<float4*>(yp) = make_float4(o0, o1, o2, o3);  // 16-B rows: checked on the host
   }
 }
@@ -209,7 +216,8 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const int32_t* __restr
                                                           const float* __restrict__ a_s, const float* __restrict__ a_d,
                                                           const float* __restrict__ alpha, float* __restrict__ de,
                                                           float* __restrict__ dad, int32_t n, int64_t Ep, int32_t B,
-                                                          int32_t H, int32_t C, int32_t nRB, int32_t xcd_map) {
+                                                          int32_t H, int32_t C, int32_t nRB, int32_t xcd_map, int32_t Hs,
+                                                          int32_t h0, int32_t Htot) {
   constexpr int RPW = 64 / LPR, RPB = RPW * 4;
   constexpr int EL = LPR < gcl::kEll ? LPR : gcl::kEll;
   // all row blocks of a sample on ONE XCD (blocks are dealt round-robin): its h rows stay in that L2
@@ -235,12 +243,12 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const int32_t* __restr
   const int cc = cc0 - h * C;  // channel inside the head = channel of dy
   const int rc = row < n ? row : n - 1;
   const float* __restrict__ Hb = Hf + (int64_t)b * bsh;
-  const float* __restrict__ as_b = a_s + (int64_t)b * n * H;
+  const float* __restrict__ as_b = a_s + (int64_t)b * n * Hs + h0;
   const int start = rowptr[rc], end = rowptr[rc + 1];
   const int cj = ecol[(int64_t)rc * gcl::kEll + (l & (EL - 1))];
-  const float ad = a_d[((int64_t)b * n + rc) * H + h];
+  const float ad = a_d[((int64_t)b * n + rc) * Hs + h0 + h];
   const float* dp = dY + (int64_t)b * bsdy + (int64_t)rc * lddy + cc;
-  const float sH = 1.f / (float)H;
+  const float sH = 1.f / (float)Htot;
   const float g0 = cact ? dp[0] * sH : 0.f, g1 = cact ? dp[1] * sH : 0.f;
   const float g2 = cact ? dp[2] * sH : 0.f, g3 = cact ? dp[3] * sH : 0.f;
   const int deg = end - start;
@@ -258,8 +266,8 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const int32_t* __restr
 #pragma unroll
     for (int k = 0; k < EL; ++k) {
       const int e = (k < deg) ? start + k : start;
-      al[k] = alpha[((int64_t)b * Ep + e) * H + h];
-      pre[k] = as_b[(int64_t)jj[k] * H + h] + ad;
+      al[k] = alpha[((int64_t)b * Ep + e) * Hs + h0 + h];
+      pre[k] = as_b[(int64_t)jj[k] * Hs + h] + ad;
     }
     float t = 0.f;
 #pragma unroll
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const int32_t* __restr
     for (int k = 0; k < EL; ++k) {
       const float dev = al[k] * (d[k] - t) * (pre[k] > 0.f ? 1.f : kNegSlope);
       sum_de += (k < deg) ? dev : 0.f;
-      if (leader && k < deg) de[((int64_t)b * Ep + start + k) * H + h] = dev;
+      if (leader && k < deg) de[((int64_t)b * Ep + start + k) * Hs + h0 + h] = dev;
     }
   } else {
     // generic path: the trip count is uniform across the lanes that shuffle together (one row group)
@@ -283,21 +291,21 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const int32_t* __restr
       const float4 v = *reinterpret_cast<const float4*>(Hb + (int64_t)col[e] * ldh + cc0);
       float d = g0 * v.x + g1 * v.y + g2 * v.z + g3 * v.w;
       for (int off = lph >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
-      t += alpha[((int64_t)b * Ep + e) * H + h] * d;
+      t += alpha[((int64_t)b * Ep + e) * Hs + h0 + h] * d;
     }
     for (int e = start; e < end; ++e) {
       const int j = col[e];
       const float4 v = *reinterpret_cast<const float4*>(Hb + (int64_t)j * ldh + cc0);
       float d = g0 * v.x + g1 * v.y + g2 * v.z + g3 * v.w;
       for (int off = lph >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
-      const float a_ = alpha[((int64_t)b * Ep + e) * H + h];
-      const float pr = as_b[(int64_t)j * H + h] + ad;
+      const float a_ = alpha[((int64_t)b * Ep + e) * Hs + h0 + h];
+      const float pr = as_b[(int64_t)j * Hs + h] + ad;
       const float dev = a_ * (d - t) * (pr > 0.f ? 1.f : kNegSlope);
       sum_de += dev;
-      if (leader) de[((int64_t)b * Ep + e) * H + h] = dev;
+      if (leader) de[((int64_t)b * Ep + e) * Hs + h0 + h] = dev;
     }
   }
-  if (leader) dad[((int64_t)b * n + row) * H + h] = sum_de;
+  if (leader) dad[((int64_t)b * n + row) * Hs + h0 + h] = sum_de;
 }
 
 // Backward, source side (transposed CSR): for source row j, head h
@@ -315,7 +323,8 @@ __global__ __launch_bounds__(256) void gat_bwd_src_kernel(const int32_t* __restr
                                                           const float* __restrict__ att_d, float* __restrict__ das,
                                                           float* __restrict__ dH, int64_t lddh, int64_t bsdh,
                                                           int32_t n, int64_t Ep, int32_t B, int32_t H, int32_t C,
-                                                          int32_t nRB, int32_t vdy, int32_t xcd_map) {
+                                                          int32_t nRB, int32_t vdy, int32_t xcd_map, int32_t Hs, int32_t h0,
+                                                          int32_t Htot) {
   constexpr int RPW = 64 / LPR, RPB = RPW * 4;
   constexpr int EL = LPR < gcl::kEll ? LPR : gcl::kEll;
   int b, rb;
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(256) void gat_bwd_src_kernel(const int32_t* __restr
   const int cc0 = cact ? c0 : 0;
   const int h = cc0 / C, cc = cc0 - h * C;
   const int rc = row < n ? row : n - 1;
-  const float s = 1.f / (float)H;
+  const float s = 1.f / (float)Htot;
   const int start = trowptr[rc], end = trowptr[rc + 1];
   const int ci = tecol[(int64_t)rc * gcl::kEll + (l & (EL - 1))];
   const int si = teslot[(int64_t)rc * gcl::kEll + (l & (EL - 1))];
@@ -363,7 +372,7 @@ __global__ __launch_bounds__(256) void gat_bwd_src_kernel(const int32_t* __restr
     for (int k = 0; k < EL; ++k) v[k] = ld_dy(ii[k]);
 #pragma unroll
     for (int k = 0; k < EL; ++k) {
-      const int64_t sl = ((int64_t)b * Ep + ss[k]) * H + h;
+      const int64_t sl = ((int64_t)b * Ep + ss[k]) * Hs + h0 + h;
       al[k] = alpha[sl];
       dk[k] = de[sl];
     }
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(256) void gat_bwd_src_kernel(const int32_t* __restr
   } else {
     for (int e = start; e < end; ++e) {
       const int i = tcol[e];
-      const int64_t sl = ((int64_t)b * Ep + tslot[e]) * H + h;
+      const int64_t sl = ((int64_t)b * Ep + tslot[e]) * Hs + h0 + h;
       const float a_ = alpha[sl] * s;
       sde += de[sl];
       const float4 v = ld_dy(i);
@@ -388,14 +397,14 @@ __global__ __launch_bounds__(256) void gat_bwd_src_kernel(const int32_t* __restr
     }
   }
   if (!active) return;
-  const float dd = dad[((int64_t)b * n + row) * H + h];
+  const float dd = dad[((int64_t)b * n + row) * Hs + h0 + h];
   a0 += sde * att_s[c0] + dd * att_d[c0];
   a1 += sde * att_s[c0 + 1] + dd * att_d[c0 + 1];
   a2 += sde * att_s[c0 + 2] + dd * att_d[c0 + 2];
   a3 += sde * att_s[c0 + 3] + dd * att_d[c0 + 3];
   float* o = dH + (int64_t)b * bsdh + (int64_t)row * lddh + c0;
   *reinterpret_cast<float4*>(o) = make_float4(a0, a1, a2, a3);  // 16-B rows: checked on the host
-  if ((l % lph) == 0) das[((int64_t)b * n + row) * H + h] = sde;
+  if ((l % lph) == 0) das[((int64_t)b * n + row) * Hs + h0 + h] = sde;
 }
 
 // part[block][2][HC]: sum_rows da_s[r,h] * h[r,hc]  |  sum_rows da_d[r,h] * h[r,hc]
@@ -403,7 +412,7 @@ template <int LPR>
 __global__ __launch_bounds__(256) void gat_datt_kernel(const float* __restrict__ Hf, int64_t ldh, int64_t bsh,
                                                        const float* __restrict__ das, const float* __restrict__ dad,
                                                        float* __restrict__ part, int32_t n, int32_t B, int32_t H,
-                                                       int32_t C) {
+                                                       int32_t C, int32_t Hs, int32_t h0) {
   constexpr int RPW = 64 / LPR, RPB = RPW * 4;
   __shared__ float red[RPB][LPR * 4 * 2 + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(256) void gat_datt_kernel(const float* __restrict__
       const int64_t b = r / n;
       const int i = (int)(r - b * n);
       const float4 v = *reinterpret_cast<const float4*>(Hf + b * bsh + (int64_t)i * ldh + c0);
-      const float ws = das[r * H + h], wd = dad[r * H + h];
+      const float ws = das[r * Hs + h0 + h], wd = dad[r * Hs + h0 + h];
       s0 += ws * v.x; s1 += ws * v.y; s2 += ws * v.z; s3 += ws * v.w;
       d0 += wd * v.x; d1 += wd * v.y; d2 += wd * v.z; d3 += wd * v.w;
     }
@@ -456,17 +465,32 @@ __global__ __launch_bounds__(256) void prune_ballot_kernel(const float* __restri
 
 constexpr int kGatBlocks = 512;
 
-int gat_check(const gcl_graph_t* g, int32_t H, int32_t C, int* lpr) {
+// Head chunking: the kernels map ALL channels of the heads they handle onto one lane group (<= 64 lanes x 4
+// channels), so one launch takes a power-of-two number of heads Hc with Hc * C <= 256.  A layer with more heads, or
+// a head count that is not a power of two (the reference reports 8 and 33 heads at C = 64, README.md:148-150),
+// runs as several launches over column blocks of h, with per-head arrays strided by the total head count.
+int gat_check(const gcl_graph_t* g, int32_t H, int32_t C, int* chunk) {
   GCL_CHECK_ARG(g, "gat: null graph");
   GCL_CHECK_ARG(H >= 1 && C >= 4 && (C % 4) == 0, "gat: C must be a positive multiple of 4 (H=%d C=%d)", H, C);
   const int lph = C / 4;
-  if ((lph & (lph - 1)) != 0 || (H & (H - 1)) != 0 || H * C > 256) {
-    gcl::set_error("gat: unsupported head geometry H=%d C=%d (need C/4 and H powers of two, H*C <= 256)", H, C);
+  if ((lph & (lph - 1)) != 0 || C > 256) {
+    gcl::set_error("gat: unsupported head width C=%d (C/4 must be a power of two, C <= 256)", C);
     return GCL_EUNSUPPORTED;
   }
-  const int lanes = H * lph;
-  *lpr = lanes <= 4 ? 4 : lanes <= 8 ? 8 : lanes <= 16 ? 16 : lanes <= 32 ? 32 : 64;
+  int hc = 1;
+  while (hc * 2 <= H && hc * 2 * C <= 256) hc *= 2;
+  *chunk = hc;  // the last chunk(s) of a non-power-of-two H are smaller powers of two
   return GCL_OK;
+}
+inline int lpr_for(int heads, int C) {
+  const int lanes = heads * (C / 4);
+  return lanes <= 4 ? 4 : lanes <= 8 ? 8 : lanes <= 16 ? 16 : lanes <= 32 ? 32 : 64;
+}
+// heads of the chunk that starts at h0
+inline int chunk_heads(int H, int h0, int maxc) {
+  int hc = maxc;
+  while (hc > H - h0) hc >>= 1;
+  return hc;
 }
 
 }  // namespace
@@ -483,8 +507,8 @@ int gat_check(const gcl_graph_t* g, int32_t H, int32_t C, int* lpr) {
 extern "C" int gcl_gat_fwd(const gcl_graph_t* g, const float* h, int64_t ldh, int64_t bsh, const float* att_src,
                            const float* att_dst, const float* bias, float* a_src, float* a_dst, float* alpha,
                            float* y, int64_t ldy, int64_t bsy, int32_t B, int32_t H, int32_t C, gcl_stream_t stream) {
-  int lpr = 0;
-  int rc = gat_check(g, H, C, &lpr);
+  int maxc = 0;
+  int rc = gat_check(g, H, C, &maxc);
   if (rc) return rc;
   GCL_CHECK_ARG(h && att_src && att_dst && a_src && a_dst && y, "gat_fwd: null argument");
   GCL_CHECK_ARG(B > 0 && ldh >= H * C && ldy >= C, "gat_fwd: bad shape");
@@ -492,25 +516,32 @@ extern "C" int gcl_gat_fwd(const gcl_graph_t* g, const float* h, int64_t ldh, in
   GCL_CHECK_ARG((ldy % 4) == 0 && (bsy % 4) == 0 && gcl::aligned16(y), "gat_fwd: y must be 16-B aligned with ld %% 4 == 0");
   GCL_CHECK_ARG(g->kind == GCL_GRAPH_GAT, "gat_fwd: graph was not created with GCL_GRAPH_GAT");
   hipStream_t st = (hipStream_t)stream;
-  const int rpb = (64 / lpr) * 4;
-  const int64_t rows = (int64_t)B * g->n;
-  int64_t nbs = gcl::cdiv(rows, rpb);
-  if (nbs > 4096) nbs = 4096;
-#define CALL(L)                                                                                                    \
-  hipLaunchKernelGGL((gat_scores_kernel<L>), dim3((unsigned)nbs), dim3(256), 0, st, h, ldh, bsh, att_src, att_dst, \
-                     a_src, a_dst, g->n, B, H, C)
-  GCL_DISPATCH_LPR(lpr, CALL)
+  for (int h0 = 0; h0 < H;) {
+    const int hc = chunk_heads(H, h0, maxc);
+    const int lpr = lpr_for(hc, C);
+    const float* hh = h + (int64_t)h0 * C;  // column block of this chunk's heads
+    const int rpb = (64 / lpr) * 4;
+    const int64_t rows = (int64_t)B * g->n;
+    int64_t nbs = gcl::cdiv(rows, rpb);
+    if (nbs > 4096) nbs = 4096;
+#define CALL(L)                                                                                                     \
+  hipLaunchKernelGGL((gat_scores_kernel<L>), dim3((unsigned)nbs), dim3(256), 0, st, hh, ldh, bsh, att_src + h0 * C, \
+                     att_dst + h0 * C, a_src, a_dst, g->n, B, hc, C, H, h0)
+    GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
-  GCL_CHECK_LAUNCH();
-  const int32_t nRB = (int32_t)gcl::cdiv(g->n, rpb);
-  const int xcd_map = B >= 8 ? 1 : 0;
-  const int64_t nb = xcd_map ? (int64_t)8 * gcl::cdiv(B, 8) * nRB : (int64_t)B * nRB;
+    GCL_CHECK_LAUNCH();
+    const int32_t nRB = (int32_t)gcl::cdiv(g->n, rpb);
+    const int xcd_map = B >= 8 ? 1 : 0;
+    const int64_t nb = xcd_map ? (int64_t)8 * gcl::cdiv(B, 8) * nRB : (int64_t)B * nRB;
 #define CALL(L)                                                                                                       \
-  hipLaunchKernelGGL((gat_fwd_kernel<L>), dim3((unsigned)nb), dim3(256), 0, st, g->rowptr, g->col, g->ecol, h, ldh, \
-                     bsh, a_src, a_dst, bias, alpha, y, ldy, bsy, g->n, g->e, B, H, C, nRB, xcd_map)
-  GCL_DISPATCH_LPR(lpr, CALL)
+  hipLaunchKernelGGL((gat_fwd_kernel<L>), dim3((unsigned)nb), dim3(256), 0, st, g->rowptr, g->col, g->ecol, hh, ldh,  \
+                     bsh, a_src, a_dst, h0 == 0 ? bias : nullptr, alpha, y, ldy, bsy, g->n, g->e, B, hc, C, nRB,      \
+                     xcd_map, H, h0, H, h0 > 0 ? 1 : 0)
+    GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
-  GCL_CHECK_LAUNCH();
+    GCL_CHECK_LAUNCH();
+    h0 += hc;
+  }
   return GCL_OK;
 }
 
@@ -529,8 +560,8 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
                            const float* a_dst, const float* alpha, float* dh, int64_t lddh, int64_t bsdh,
                            float* d_att_src, float* d_att_dst, float* d_bias, int32_t accumulate, int32_t B, int32_t H,
                            int32_t C, void* ws, size_t ws_bytes, gcl_stream_t stream) {
-  int lpr = 0;
-  int rc = gat_check(g, H, C, &lpr);
+  int maxc = 0;
+  int rc = gat_check(g, H, C, &maxc);
   if (rc) return rc;
   GCL_CHECK_ARG(dy && h && att_src && att_dst && a_src && a_dst && alpha && dh && d_att_src && d_att_dst,
                 "gat_bwd: null argument");
@@ -546,36 +577,43 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
   float* das = dad + (size_t)B * g->n * H;
   float* part = das + (size_t)B * g->n * H;
   float* cs_ws = part + (size_t)kGatBlocks * 2 * H * C;
-  const int rpb = (64 / lpr) * 4;
-  const int32_t nRB = (int32_t)gcl::cdiv(g->n, rpb);
   const int xcd_map = B >= 8 ? 1 : 0;
-  const unsigned nb = (unsigned)(xcd_map ? (int64_t)8 * gcl::cdiv(B, 8) * nRB : (int64_t)B * nRB);
   const int vdy = (lddy % 4 == 0) && (bsdy % 4 == 0) && (C % 4 == 0) && gcl::aligned16(dy);
+  const int64_t rows = (int64_t)B * g->n;
+  for (int h0 = 0; h0 < H;) {
+    const int hc = chunk_heads(H, h0, maxc);
+    const int lpr = lpr_for(hc, C);
+    const int rpb = (64 / lpr) * 4;
+    const int32_t nRB = (int32_t)gcl::cdiv(g->n, rpb);
+    const unsigned nb = (unsigned)(xcd_map ? (int64_t)8 * gcl::cdiv(B, 8) * nRB : (int64_t)B * nRB);
+    const float* hh = h + (int64_t)h0 * C;
 #define CALL(L)                                                                                                    \
   hipLaunchKernelGGL((gat_bwd_dst_kernel<L>), dim3(nb), dim3(256), 0, st, g->rowptr, g->col, g->ecol, dy, lddy,     \
-                     bsdy, h, ldh, bsh, a_src, a_dst, alpha, de, dad, g->n, g->e, B, H, C, nRB, xcd_map)
-  GCL_DISPATCH_LPR(lpr, CALL)
+                     bsdy, hh, ldh, bsh, a_src, a_dst, alpha, de, dad, g->n, g->e, B, hc, C, nRB, xcd_map, H, h0, H)
+    GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
-  GCL_CHECK_LAUNCH();
+    GCL_CHECK_LAUNCH();
 #define CALL(L)                                                                                                       \
   hipLaunchKernelGGL((gat_bwd_src_kernel<L>), dim3(nb), dim3(256), 0, st, g->trowptr, g->tcol, g->tslot, g->tecol,    \
-                     g->teslot, dy, lddy, bsdy, alpha, de, dad, att_src, att_dst, das, dh, lddh, bsdh, g->n, g->e, B, \
-                     H, C, nRB, vdy, xcd_map)
-  GCL_DISPATCH_LPR(lpr, CALL)
+                     g->teslot, dy, lddy, bsdy, alpha, de, dad, att_src + h0 * C, att_dst + h0 * C, das,              \
+                     dh + (int64_t)h0 * C, lddh, bsdh, g->n, g->e, B, hc, C, nRB, vdy, xcd_map, H, h0, H)
+    GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
-  GCL_CHECK_LAUNCH();
-  const int64_t rows = (int64_t)B * g->n;
-  int64_t nbd = gcl::cdiv(rows, rpb);
-  if (nbd > kGatBlocks) nbd = kGatBlocks;
-#define CALL(L)                                                                                                 \
-  hipLaunchKernelGGL((gat_datt_kernel<L>), dim3((unsigned)nbd), dim3(256), 0, st, h, ldh, bsh, das, dad, part, g->n, \
-                     B, H, C)
-  GCL_DISPATCH_LPR(lpr, CALL)
+    GCL_CHECK_LAUNCH();
+    int64_t nbd = gcl::cdiv(rows, rpb);
+    if (nbd > kGatBlocks) nbd = kGatBlocks;
+#define CALL(L)                                                                                                    \
+  hipLaunchKernelGGL((gat_datt_kernel<L>), dim3((unsigned)nbd), dim3(256), 0, st, hh, ldh, bsh, das, dad, part, g->n, \
+                     B, hc, C, H, h0)
+    GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
-  GCL_CHECK_LAUNCH();
-  const int HC = H * C;
-  rc = gcl::launch_reduce_parts2(part, (int)nbd, 2 * HC, HC, HC, d_att_src, d_att_dst, HC, accumulate, st);
-  if (rc) return rc;
+    GCL_CHECK_LAUNCH();
+    const int HC = hc * C;
+    rc = gcl::launch_reduce_parts2(part, (int)nbd, 2 * HC, HC, HC, d_att_src + h0 * C, d_att_dst + h0 * C, HC, accumulate,
+                                   st);
+    if (rc) return rc;
+    h0 += hc;
+  }
   if (d_bias) {
     // dy rows are contiguous across the batch (checked above): one flat column sum
     rc = gcl_colsum(dy, lddy, rows, C, d_bias, accumulate, cs_ws, gcl_colsum_ws_bytes(rows, C), stream);

@@ -1482,7 +1482,9 @@ static bool fused_ok(const float* dy, int64_t lddy, const float* x, int64_t ldx,
     off = (e && atoi(e) != 0) ? 1 : 0;
   }
   if (off || use_valu()) return false;
-  return Fout <= 64 && Fin <= 96 && (Fout % 4 == 0) && (Fin % 4 == 0) && (lddy % 4 == 0) && (ldx % 4 == 0) &&
+  // Fout need not be a multiple of 4 when the rows of dy are padded to one (lddy >= roundup(Fout, 4)): the 16-byte
+  // loads then also fetch the padding columns, which meet zero weight rows (they must hold finite values)
+  return Fout <= 64 && Fin <= 96 && (lddy >= ((Fout + 3) & ~3)) && (Fin % 4 == 0) && (lddy % 4 == 0) && (ldx % 4 == 0) &&
          (lddx >= Fin) && gcl::aligned16(dy) && gcl::aligned16(x) && dx != nullptr;
 }
 

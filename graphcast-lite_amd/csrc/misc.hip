@@ -59,14 +59,17 @@ __global__ __launch_bounds__(256) void wmse_kernel(const float* __restrict__ del
 }
 
 __global__ void wmse_final_kernel(const float* __restrict__ part, int32_t nparts, float inv_wsum,
-                                  float* __restrict__ loss) {
+                                  const float* __restrict__ loss_prev, float* __restrict__ loss) {
   __shared__ double red[4];
   double s = 0.0;
   for (int p = threadIdx.x; p < nparts; p += 256) s += (double)part[p];
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) *loss = (float)((red[0] + red[1] + red[2] + red[3]) * (double)inv_wsum);
+  if (threadIdx.x == 0) {
+    const float l = (float)((red[0] + red[1] + red[2] + red[3]) * (double)inv_wsum);
+    *loss = loss_prev ? *loss_prev + l : l;  // running sum over the autoregressive steps of one batch
+  }
 }
 
 // torch.optim.Adam (no amsgrad, no maximize): src/main.py:212
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) void gather2_kernel(const float* __restrict__ 
 //   out[b, g, out_off + c] = step_out;  new_state[..., k, :] = state[..., k+1, :], last slot = step_out
 // chan_kind[c]: 0 = predicted, 1 = static (carry forward), 2 = forcing (from y_step when given).
 __global__ __launch_bounds__(256) void ar_advance_kernel(const float* __restrict__ state,
-                                                         const float* __restrict__ delta,
+                                                         const float* __restrict__ delta, int64_t ldd, int64_t bsd,
                                                          const float* __restrict__ y_step, int64_t ldy, int64_t bsy,
                                                          const int32_t* __restrict__ chan_kind,
                                                          float* __restrict__ new_state, float* __restrict__ out,
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256) void ar_advance_kernel(const float* __restrict
       const int g = (int)(bg % G);
       const int64_t b = bg / G;
       const float xl = state[idx];
-      float v = delta[bg * C + c];
+      float v = delta[b * bsd + (int64_t)g * ldd + c];
       if (residual) v += xl;
       const int kind = chan_kind ? chan_kind[c] : 0;
       if (kind == 1) v = xl;
@@ -239,6 +242,57 @@ __global__ __launch_bounds__(256) void window_pack_kernel(const _Float16* __rest
   }
 }
 
+// Backward of one autoregressive training step (loss of the step + window advance; src/train.py:203-228).
+//   forward:  pred = residual ? x_last + delta : delta;  loss += sum(w (pred - y)^2) * inv;   dd = d loss / d pred
+//             new_state = shift(state), last slot = pred (static channels: x_last, forcing channels: y)
+//   backward: d_delta[c]     = g_loss * dd[c] + m_delta[c] * g_new[last, c]
+//             d_state[t, c]  = (t >= 1 ? g_new[t-1, c] : 0)
+//                              + (t == obs-1 ? (residual ? g_loss * dd[c] : 0) + m_state[c] * g_new[last, c] : 0)
+//   with, per channel kind (0 predicted, 1 static, 2 forcing-from-y):  m_delta = {1, 0, 0},  m_state = {residual, 1, 0};
+//   a forcing channel WITHOUT y behaves as a predicted one.  g_loss is a device scalar, g_new may be NULL (last step).
+__global__ __launch_bounds__(256) void ar_step_bwd_kernel(const float* __restrict__ dd, const float* __restrict__ g_loss,
+                                                          const float* __restrict__ g_new,
+                                                          const int32_t* __restrict__ chan_kind, int32_t has_y,
+                                                          int32_t residual, float* __restrict__ d_delta,
+                                                          float* __restrict__ d_state, int32_t B, int32_t G, int32_t obs,
+                                                          int32_t C) {
+  const float gl = g_loss ? *g_loss : 1.f;
+  const int64_t total = (int64_t)B * G * obs * C;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const int k = (int)((idx / C) % obs);
+    const int64_t bg = idx / ((int64_t)C * obs);
+    float ds = (g_new && k >= 1) ? g_new[idx - C] : 0.f;
+    if (k == obs - 1) {
+      int kind = chan_kind ? chan_kind[c] : 0;
+      if (kind == 2 && !has_y) kind = 0;
+      const float gd = gl * dd[bg * C + c];
+      const float gn = g_new ? g_new[idx] : 0.f;
+      d_delta[bg * C + c] = gd + (kind == 0 ? gn : 0.f);
+      ds += (residual ? gd : 0.f) + ((kind == 1 || (kind == 0 && residual)) ? gn : 0.f);
+    }
+    if (d_state) d_state[idx] = ds;
+  }
+}
+
+// dst[b, i, c] = (i < rows_src && c < F_src) ? src[b, i, c] : 0   for i < rows_dst, c < F_dst: widens a gradient to the
+// zero-padded layout of a layer whose output was returned as a row / column slice (the decoder returns the grid rows
+// and the first 33 / 19 columns of its last, 36- / 20-wide conv: src/models.py:870-872).
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, int64_t lds, int64_t bss,
+                                                       int32_t rows_src, int32_t F_src, float* __restrict__ dst,
+                                                       int64_t ldd, int64_t bsd, int32_t rows_dst, int32_t F_dst,
+                                                       int32_t B) {
+  const int64_t total = (int64_t)B * rows_dst * F_dst;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c = (int)(idx % F_dst);
+    const int64_t br = idx / F_dst;
+    const int r = (int)(br % rows_dst);
+    const int64_t b = br / rows_dst;
+    const bool in = r < rows_src && c < F_src;
+    dst[b * bsd + (int64_t)r * ldd + c] = in ? src[b * bss + (int64_t)r * lds + c] : 0.f;
+  }
+}
+
 inline unsigned grid_for(int64_t total, int cap = 4096) {
   int64_t nb = gcl::cdiv(total > 0 ? total : 1, 256);
   return (unsigned)(nb > cap ? cap : nb);
@@ -266,8 +320,8 @@ extern "C" size_t gcl_wmse_ws_bytes(int32_t B, int32_t G, int32_t C) {
 extern "C" int gcl_wmse_fwd_bwd(const float* delta, int64_t ldd, int64_t bsd, const float* x_last, int64_t ldx,
                                 int64_t bsx, const float* y, int64_t ldy, int64_t bsy, const float* node_w,
                                 const float* chan_w, float inv_wsum, float grad_scale, float* d_delta,
-                                float* out_state, float* loss_out, int32_t B, int32_t G, int32_t C, void* ws,
-                                size_t ws_bytes, gcl_stream_t stream) {
+                                float* out_state, const float* loss_prev, float* loss_out, int32_t B, int32_t G,
+                                int32_t C, void* ws, size_t ws_bytes, gcl_stream_t stream) {
   GCL_CHECK_ARG(delta && y && loss_out, "wmse: null argument");
   GCL_CHECK_ARG(B > 0 && G > 0 && C > 0 && ldd >= C && ldy >= C && (!x_last || ldx >= C), "wmse: bad shape");
   GCL_CHECK_ARG(ws && ws_bytes >= gcl_wmse_ws_bytes(B, G, C), "wmse: workspace too small");
@@ -276,7 +330,8 @@ extern "C" int gcl_wmse_fwd_bwd(const float* delta, int64_t ldd, int64_t bsd, co
   const unsigned nb = grid_for(total, kLossBlocks);
   hipLaunchKernelGGL(wmse_kernel, dim3(nb), dim3(256), 0, st, delta, ldd, bsd, x_last, ldx, bsx, y, ldy, bsy, node_w,
                      chan_w, inv_wsum, grad_scale, d_delta, out_state, (float*)ws, B, G, C);
-  hipLaunchKernelGGL(wmse_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, (int)nb, inv_wsum, loss_out);
+  hipLaunchKernelGGL(wmse_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, (int)nb, inv_wsum, loss_prev,
+                     loss_out);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
@@ -339,17 +394,49 @@ extern "C" int gcl_adam_step_dev(float* p, const float* g, float* m, float* v, i
   return GCL_OK;
 }
 
-extern "C" int gcl_ar_advance(const float* state, const float* delta, const float* y_step, int64_t ldy, int64_t bsy,
-                              const int32_t* chan_kind, float* new_state, float* out, int64_t ldo, int64_t bso,
-                              int32_t out_off, int32_t B, int32_t G, int32_t obs, int32_t C, int32_t residual,
-                              gcl_stream_t stream) {
+extern "C" int gcl_ar_step_bwd(const float* dd, const float* g_loss, const float* g_new, const int32_t* chan_kind,
+                               int32_t has_y, int32_t residual, float* d_delta, float* d_state, int32_t B, int32_t G,
+                               int32_t obs, int32_t C, gcl_stream_t stream) {
+  GCL_CHECK_ARG(dd && d_delta, "ar_step_bwd: null argument");
+  GCL_CHECK_ARG(B > 0 && G > 0 && obs >= 1 && C > 0, "ar_step_bwd: bad shape");
+  const int64_t total = (int64_t)B * G * obs * C;
+  hipLaunchKernelGGL(ar_step_bwd_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, dd, g_loss,
+                     g_new, chan_kind, has_y, residual, d_delta, d_state, B, G, obs, C);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+extern "C" int gcl_pad_rows(const float* src, int64_t lds, int64_t bss, int32_t rows_src, int32_t F_src, float* dst,
+                            int64_t ldd, int64_t bsd, int32_t rows_dst, int32_t F_dst, int32_t B, gcl_stream_t stream) {
+  GCL_CHECK_ARG(src && dst, "pad_rows: null argument");
+  GCL_CHECK_ARG(B > 0 && rows_src >= 0 && rows_dst >= rows_src && F_src >= 0 && F_dst >= F_src && lds >= F_src && ldd >= F_dst,
+                "pad_rows: bad shape");
+  const int64_t total = (int64_t)B * rows_dst * F_dst;
+  if (total > 0)
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, src, lds, bss,
+                       rows_src, F_src, dst, ldd, bsd, rows_dst, F_dst, B);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+extern "C" int gcl_zero(void* ptr, size_t nbytes, gcl_stream_t stream) {
+  GCL_CHECK_ARG(ptr || nbytes == 0, "zero: null argument");
+  if (nbytes) GCL_CHECK_HIP(hipMemsetAsync(ptr, 0, nbytes, (hipStream_t)stream));
+  return GCL_OK;
+}
+
+extern "C" int gcl_ar_advance(const float* state, const float* delta, int64_t ldd, int64_t bsd, const float* y_step,
+                              int64_t ldy, int64_t bsy, const int32_t* chan_kind, float* new_state, float* out,
+                              int64_t ldo, int64_t bso, int32_t out_off, int32_t B, int32_t G, int32_t obs, int32_t C,
+                              int32_t residual, gcl_stream_t stream) {
   GCL_CHECK_ARG(state && delta && new_state, "ar_advance: null argument");
+  GCL_CHECK_ARG(ldd >= C, "ar_advance: delta row stride smaller than C");
   GCL_CHECK_ARG(state != new_state, "ar_advance: the window shift cannot be done in place");
   GCL_CHECK_ARG(B > 0 && G > 0 && obs >= 1 && C > 0, "ar_advance: bad shape");
   GCL_CHECK_ARG(!out || (ldo >= out_off + C), "ar_advance: output row too short for out_off + C");
   const int64_t total = (int64_t)B * G * obs * C;
   hipLaunchKernelGGL(ar_advance_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, state, delta,
-                     y_step, ldy, bsy, chan_kind, new_state, out, ldo, bso, out_off, B, G, obs, C, residual);
+                     ldd, bsd, y_step, ldy, bsy, chan_kind, new_state, out, ldo, bso, out_off, B, G, obs, C, residual);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

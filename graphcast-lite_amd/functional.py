@@ -122,7 +122,10 @@ class MLPFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 class GCNStackFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, owner, graph, L: int, has_ln: bool, eps: float, *params):
+    def forward(ctx, x, owner, graph, L: int, has_ln: bool, eps: float, out_rows: int, *params):
+        """out_rows > 0: only the first `out_rows` rows are returned (the decoder keeps the grid rows,
+        src/models.py:870-872); the slice is part of this Function so that its backward receives the gradient of
+        the slice and widens it with ONE pass of gcl_pad_rows (no zero-fill + copy by autograd)."""
         squeeze = x.dim() == 2
         x3 = _flat3(x.detach())
         B, n, _ = x3.shape
@@ -174,16 +177,23 @@ class GCNStackFn(torch.autograd.Function):
             out = o2.view(B, n, -1)
         ctx.owner, ctx.graph, ctx.L, ctx.has_ln = owner, graph, L, has_ln
         ctx.x3, ctx.ps, ctx.stats, ctx.params, ctx.squeeze = x3, ps, stats, params, squeeze
+        ctx.n_rows, ctx.out_rows = n, (int(out_rows) if out_rows and out_rows < n else 0)
+        if ctx.out_rows:
+            out = out[:, :ctx.out_rows, :]
         return out[0] if squeeze else out
 
     @staticmethod
     def backward(ctx, dy):
         params, L, graph = ctx.params, ctx.L, ctx.graph
-        needs = list(ctx.needs_input_grad[6:])
+        needs = list(ctx.needs_input_grad[7:])
         G = _Grads(list(params), needs)
         dy3 = _flat3(dy)
-        B, n, _ = dy3.shape
+        B, n = dy3.shape[0], ctx.n_rows
         ps = ctx.ps
+        pad = ctx.pad_last
+        dy_rows = dy3  # gradient of the rows that were returned (bias gradient of the last conv sums these)
+        if ctx.out_rows and (ctx.has_ln or pad is None):
+            dy3 = hip.pad_rows(dy3, n, dy3.shape[2])  # rows that were not returned carry a zero gradient
         if ctx.has_ln:
             gi, bi = len(params) - 2, len(params) - 1
             dgam = G.dst[gi] if G.dst[gi] is not None else torch.zeros_like(params[gi])
@@ -196,47 +206,39 @@ class GCNStackFn(torch.autograd.Function):
         dsl = G.dst[si] if params[si] is not None else None
         slope_t, akind = ctx.slope_t, ctx.akind
         dx = None
-        pad = ctx.pad_last
-        if pad is not None:  # widen the incoming gradient to the padded width (extra columns 0)
-            Fp, Fo, Wp = pad
-            if Wp is None:  # (the fused forward needed no padded copy of the weight)
-                Wp = torch.nn.functional.pad(params[2 * (L - 1)].detach(), (0, 0, 0, Fp - Fo))
-                pad = (Fp, Fo, Wp)
-            dp = torch.nn.functional.pad(dy3, (0, Fp - Fo))  # one pass: copy + zero columns
+        Fo = params[2 * (L - 1)].shape[0]
+        Fp = Fo
+        if pad is not None:
+            # The last conv ran Fp = roundup(Fout, 4) wide (zero padding columns).  Its gradient is widened to that
+            # layout (extra rows / columns 0) in one pass; the dense backward then reads it Fout wide with row stride Fp
+            # - the padding columns only ever meet zero weights - so dW / dX need no padded weight copy.
+            Fp = pad[0]
+            dp = hip.pad_rows(dy_rows if not ctx.has_ln else dp, n, Fp)
         bi_last = 2 * L - 1
         if G.dst[bi_last] is not None:  # bias of the last conv: its dp comes from outside this stack
-            if pad is None:
-                hip.colsum(dp.reshape(B * n, -1), G.dst[bi_last], G.acc[bi_last])
-            else:
-                tmp = hip.colsum(dp.view(B * n, -1), dp.new_empty(pad[0]), False)[:pad[1]]
-                G.dst[bi_last].add_(tmp) if G.acc[bi_last] else G.dst[bi_last].copy_(tmp)
+            src = dy_rows if not ctx.has_ln else dp[..., :Fo]
+            hip.colsum(src.reshape(-1, Fo), G.dst[bi_last], G.acc[bi_last])
         for k in range(L - 1, -1, -1):
             W = params[2 * k].detach()
             wi = 2 * k
             inp = (ctx.x3 if k == 0 else ps[k - 1]).view(B * n, -1)
             dh2 = hip.aggregate(graph, dp, None, transpose=True).view(B * n, -1)
+            if k == L - 1 and Fp != Fo:
+                dh2 = dh2[:, :Fo]  # [rows, Fout] view with row stride Fp
             dW = G.dst[wi] if G.dst[wi] is not None else torch.zeros_like(params[wi])
-            padded = pad is not None and k == L - 1
-            acc_w = G.acc[wi]
-            if padded:  # gradient of the padded weight goes to a scratch, its first Fout rows to the parameter
-                W, dW_real = pad[2], dW
-                dW = torch.empty_like(W)
-                acc_w = False  # the scratch is overwritten; every OTHER destination keeps its own flag
             if k > 0:
                 # one fused launch: dp_{k-1} (with PReLU'), dW_k, d(slope) and the bias gradient of
                 # conv k-1 (= column sums of dp_{k-1}), which accumulates by ITS parameter's state
-                dp = hip.linear_bwd_all(dh2, W, inp, slope_t, dsl, dW, None, G.dst[2 * k - 1], acc_w,
+                dp = hip.linear_bwd_all(dh2, W, inp, slope_t, dsl, dW, None, G.dst[2 * k - 1], G.acc[wi],
                                         acc_colsum=G.acc[2 * k - 1], act=akind).view(B, n, -1)
             elif ctx.needs_input_grad[0]:
-                dx = hip.linear_bwd_all(dh2, W, inp, None, None, dW, None, None, acc_w,
+                dx = hip.linear_bwd_all(dh2, W, inp, None, None, dW, None, None, G.acc[wi],
                                         act=hip.ACT_NONE).view(B, n, -1)
             else:
-                hip.linear_bwd_dw(dh2, inp, None, dW, None, acc_w)
-            if padded:
-                dW_real.add_(dW[:pad[1]]) if G.acc[wi] else dW_real.copy_(dW[:pad[1]])
+                hip.linear_bwd_dw(dh2, inp, None, dW, None, G.acc[wi])
         if dx is not None and ctx.squeeze:
             dx = dx[0]
-        return (dx, None, None, None, None, None) + G.out()
+        return (dx, None, None, None, None, None, None) + G.out()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -400,6 +402,40 @@ class WeightedMSEFn(torch.autograd.Function):
         return d, (d if ctx.needs_input_grad[1] else None), None, None, None, None
 
 
+class ARStepLossFn(torch.autograd.Function):
+    """One autoregressive step of the training loop (src/train.py:203-228) as ONE differentiable unit:
+    loss_out = loss_prev + weighted MSE(residual ? x_last + delta : delta, y_step) and, when `advance`, the window
+    rolled forward (static channels carried, forcing channels from y).  Forward = gcl_wmse_fwd_bwd + gcl_ar_advance,
+    backward = ONE gcl_ar_step_bwd pass producing d_delta and d_state (the upstream loss gradient is read on the
+    device): no torch arithmetic, clone, per-channel writes or cat on the differentiated path."""
+
+    @staticmethod
+    def forward(ctx, state4, delta3, y3, loss_prev, node_w, chan_w, inv_wsum: float, kinds, residual: bool,
+                advance: bool):
+        st = state4.detach()
+        if not st.is_contiguous():
+            st = st.contiguous()
+        B, G, obs, Cc = st.shape
+        d3 = delta3.detach()
+        if d3.stride(2) != 1:
+            d3 = d3.contiguous()
+        x_last = st[:, :, obs - 1, :] if residual else None
+        loss, dd, _ = hip.wmse_fwd_bwd(d3, x_last, y3, node_w, chan_w, inv_wsum, 1.0, want_grad=True,
+                                       loss_prev=loss_prev.detach() if loss_prev is not None else None)
+        new_state = hip.ar_advance(st, d3, y3, kinds, None, 0, residual) if advance else st.new_empty(0)
+        ctx.dd, ctx.kinds, ctx.residual, ctx.advance, ctx.obs, ctx.has_y = dd, kinds, residual, advance, obs, y3 is not None
+        if not advance:
+            ctx.mark_non_differentiable(new_state)
+        return loss, new_state
+
+    @staticmethod
+    def backward(ctx, g_loss, g_new):
+        g_new = g_new if (ctx.advance and g_new is not None and g_new.numel()) else None
+        d_delta, d_state = hip.ar_step_bwd(ctx.dd, g_loss, g_new, ctx.kinds, ctx.has_y, ctx.residual, ctx.obs,
+                                           want_state=ctx.needs_input_grad[0])
+        return d_state, d_delta, None, (g_loss if ctx.needs_input_grad[3] else None), None, None, None, None, None, None
+
+
 class Gather2Fn(torch.autograd.Function):
     """Row gather from two sources with precomputed index maps (see hip.gather2_rows).
     maps = (map_a, map_b, inv_a, inv_b): forward maps have length nd; inv_x[j] = destination row
@@ -478,7 +514,9 @@ class InteractionNetFn(torch.autograd.Function):
         B, n, D = x3.shape
         E = lay.E
         P = [p.detach() if p is not None else None for p in params]
-        slope_enc = P[2]
+        # ReLU (src/models.py:154-163) runs as a PReLU with the owner's constant zero slope (no slope gradient)
+        cs = getattr(owner, "const_slope", None)
+        slope_enc = P[2] if P[2] is not None else cs
         e0pre = hip.dense_fwd(raw_edges, P[0], P[1])                       # [E, D]  batch-invariant
         e0 = hip.act_fwd(e0pre, act, slope_enc)
         e = e0.unsqueeze(0) if B == 1 else e0.unsqueeze(0).expand(B, E, D).contiguous()
@@ -486,6 +524,7 @@ class InteractionNetFn(torch.autograd.Function):
         xc = x3
         for k in range(n_steps):
             We1, be1, We2, be2, Wn1, bn1, Wn2, bn2, slope, ge, bte, gn, btn = P[3 + 13 * k: 16 + 13 * k]
+            slope = slope if slope is not None else cs
             last = k == n_steps - 1
             x2, e2 = xc.view(B * n, D), e.view(B * E, D)
             # edge update
@@ -518,7 +557,7 @@ class InteractionNetFn(torch.autograd.Function):
             if not last:
                 e = e_next
         ctx.owner, ctx.lay, ctx.raw, ctx.n_steps, ctx.act, ctx.use_ln, ctx.eps = owner, lay, raw_edges, n_steps, act, use_ln, eps
-        ctx.params, ctx.saved, ctx.e0pre, ctx.squeeze, ctx.dims = params, saved, e0pre, squeeze, (B, n, D, E)
+        ctx.params, ctx.saved, ctx.e0pre, ctx.squeeze, ctx.dims, ctx.cs = params, saved, e0pre, squeeze, (B, n, D, E), cs
         return xc[0] if squeeze else xc
 
     @staticmethod
@@ -537,6 +576,7 @@ class InteractionNetFn(torch.autograd.Function):
         for k in range(ctx.n_steps - 1, -1, -1):
             o = 3 + 13 * k
             We1, be1, We2, be2, Wn1, bn1, Wn2, bn2, slope, ge, bte, gn, btn = P[o: o + 13]
+            slope = slope if slope is not None else ctx.cs
             xc, e, H, agg, epre, estats, Hn, xpre, xstats = ctx.saved[k]
             ctx.saved[k] = None
             x2, e2, H2 = xc.view(B * n, D), e.view(B * E, D), H.view(B * E, D)
@@ -577,7 +617,7 @@ class InteractionNetFn(torch.autograd.Function):
             de = de_in.view(B, E, D)
         # edge encoder (batch-invariant: its gradient is the sum over samples)
         de0 = de[0] if B == 1 else de.sum(dim=0)
-        de0pre = hip.act_bwd(ctx.e0pre, de0.contiguous(), act, P[2], dst(2))
+        de0pre = hip.act_bwd(ctx.e0pre, de0.contiguous(), act, P[2] if P[2] is not None else ctx.cs, dst(2))
         hip.dense_bwd_dw(de0pre, ctx.raw, dst(0), dst(1), G.acc[0])
         gx = None
         if ctx.needs_input_grad[0]:

@@ -58,7 +58,10 @@ _SIGNATURES = {
     "gcl_colsum_ws_bytes": (_sz, [_i64, _i32]),
     "gcl_assemble_input": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "gcl_wmse_fwd_bwd": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f32, _f32, _vp,
-                                   _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+                                   _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "gcl_ar_step_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "gcl_pad_rows": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "gcl_zero": (C.c_int, [_vp, _sz, _vp]),
     "gcl_wmse_ws_bytes": (_sz, [_i32, _i32, _i32]),
     "gcl_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     "gcl_adam_step_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _vp]),
@@ -75,8 +78,8 @@ _SIGNATURES = {
     "gcl_act_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, C.c_size_t, _vp]),
     "gcl_act_bwd_ws_bytes": (C.c_size_t, []),
     "gcl_window_pack": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
-    "gcl_ar_advance": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32,
-                                 _i32, _vp]),
+    "gcl_ar_advance": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32,
+                                 _i32, _i32, _vp]),
     "gcl_gather2_rows": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
 }
 
@@ -253,10 +256,19 @@ def linear_bwd_dw(dy, x, in_slope, dW, db, accumulate: bool, act=None):
 ACT_NONE, ACT_PRELU, ACT_SILU = 0, 1, 2
 
 
-# bench.py sets this to {"rows": r, "Fin": k, "Fout": n, "events": []} to time the dense launches of
-# that shape (the edge-MLP contractions of the InteractionNet processor) with HIP events recorded on
-# the launch stream.
-DENSE_PROFILE = None
+# Optional launch probe (None in the product): measurement code (bench.py) may install an object with
+# `begin(kind, **info) -> token | None` and `end(token)`; the wrappers of the roofline kernels call it around
+# their launch so that HIP events can be recorded on the launch stream without any profiling state here.
+PROBE = None
+
+
+def _probe_begin(kind, **info):
+    return PROBE.begin(kind, **info) if PROBE is not None else None
+
+
+def _probe_end(tok):
+    if tok is not None:
+        PROBE.end(tok)
 
 
 def dense_fwd(x, W, bias, act=ACT_NONE, slope=None, addend=None, out=None):
@@ -269,16 +281,10 @@ def dense_fwd(x, W, bias, act=ACT_NONE, slope=None, addend=None, out=None):
         out = torch.empty(rows, Fout, dtype=torch.float32, device=x.device)
     if rows == 0:  # an empty batch of rows: nothing to launch (empty tensors have no device pointer)
         return out
-    prof = DENSE_PROFILE
-    prof = prof is not None and prof["rows"] == rows and prof["Fin"] == Fin and prof["Fout"] == Fout
-    if prof:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    tok = _probe_begin("dense_fwd", rows=rows, Fin=Fin, Fout=Fout)
     _check(lib().gcl_dense_fwd(_p(x), _ld(x), int(act), _p(slope), _p(W), W.stride(0), _p(bias), _p(addend),
                                _ld(addend) if addend is not None else 0, _p(out), _ld(out), rows, Fin, Fout, _stream()))
-    if prof:
-        e1.record()
-        DENSE_PROFILE["events"].append((e0, e1))
+    _probe_end(tok)
     return out
 
 
@@ -314,11 +320,6 @@ def dense_bwd_dw(dy, x, dW, db, accumulate: bool, act=ACT_NONE, slope=None):
     ws = workspace(nb, dy.device)
     _check(lib().gcl_dense_bwd_dw(_p(dy), _ld(dy), _p(x), _ld(x), int(act), _p(slope), _p(dW), dW.stride(0), _p(db), rows,
                                   Fin, Fout, 1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()))
-
-
-# bench.py sets this to {"graph": Graph, "events": []} to time the forward aggregation launches of
-# one graph with HIP events recorded on the launch stream (BENCH roofline line).
-AGG_PROFILE = None
 
 
 ACC_DW, ACC_DB, ACC_COLSUM = 1, 2, 4  # GCL_ACC_* bits of gcl_linear_bwd_all
@@ -362,15 +363,10 @@ def aggregate(graph: Graph, h3, bias, transpose=False, out=None):
     assert h3.stride(2) == 1
     if out is None:
         out = torch.empty(B, n, F, dtype=torch.float32, device=h3.device)
-    prof = AGG_PROFILE is not None and AGG_PROFILE["graph"] is graph and not transpose
-    if prof:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    tok = _probe_begin("aggregate", graph=graph, transpose=bool(transpose), B=B, F=F)
     _check(lib().gcl_aggregate(graph.handle, 1 if transpose else 0, _p(h3), h3.stride(1), h3.stride(0), _p(bias),
                                _p(out), out.stride(1), out.stride(0), B, F, _stream()))
-    if prof:
-        e1.record()
-        AGG_PROFILE["events"].append((e0, e1))
+    _probe_end(tok)
     return out
 
 
@@ -473,7 +469,8 @@ def assemble_input(x3, grid_static, mesh_static):
     return out
 
 
-def wmse_fwd_bwd(delta3, x_last3, y3, node_w, chan_w, inv_wsum, grad_scale, want_grad=True, want_state=False):
+def wmse_fwd_bwd(delta3, x_last3, y3, node_w, chan_w, inv_wsum, grad_scale, want_grad=True, want_state=False,
+                 loss_prev=None):
     """delta3 [B,G,C] contiguous; x_last3 / y3 may be strided views (unit channel stride)."""
     B, G, Cc = delta3.shape
     dev = delta3.device
@@ -488,7 +485,7 @@ def wmse_fwd_bwd(delta3, x_last3, y3, node_w, chan_w, inv_wsum, grad_scale, want
     _check(lib().gcl_wmse_fwd_bwd(
         _p(delta3), delta3.stride(1), delta3.stride(0), _p(xl), xl.stride(1) if xl is not None else 0, xl.stride(0) if xl is not None else 0,
         _p(y3), y3.stride(1), y3.stride(0), _p(node_w), _p(chan_w), float(inv_wsum), float(grad_scale), _p(dd), _p(st),
-        _p(loss), B, G, Cc, ws.data_ptr(), ws.numel(), _stream()))
+        _p(loss_prev), _p(loss), B, G, Cc, ws.data_ptr(), ws.numel(), _stream()))
     return loss, dd, st
 
 
@@ -531,13 +528,43 @@ def gather2_rows(a3, map_a, b3, map_b, nd: int, B: int, sum_batch: bool = False)
 def ar_advance(state4, delta3, y_step3, chan_kind, out3, out_off: int, residual: bool):
     """state4 [B,G,obs,C] contiguous -> new state (same shape); appends the step to out3 [B,G,steps*C]."""
     B, G, obs, Cc = state4.shape
+    assert state4.is_contiguous() and delta3.stride(2) == 1
     new_state = torch.empty_like(state4)
     _check(lib().gcl_ar_advance(
-        _p(state4), _p(delta3.contiguous()), _p(y_step3), y_step3.stride(1) if y_step3 is not None else 0,
+        _p(state4), _p(delta3), delta3.stride(1), delta3.stride(0), _p(y_step3), y_step3.stride(1) if y_step3 is not None else 0,
         y_step3.stride(0) if y_step3 is not None else 0, _pi(chan_kind), _p(new_state), _p(out3),
         out3.stride(1) if out3 is not None else 0, out3.stride(0) if out3 is not None else 0, int(out_off), B, G, obs, Cc,
         1 if residual else 0, _stream()))
     return new_state
+
+
+def ar_step_bwd(dd3, g_loss, g_new4, chan_kind, has_y: bool, residual: bool, obs: int, want_state: bool):
+    """Backward of one autoregressive training step (see gcl_ar_step_bwd): (d_delta [B,G,C], d_state [B,G,obs,C] | None)."""
+    B, G, Cc = dd3.shape
+    d_delta = torch.empty_like(dd3)
+    d_state = torch.empty(B, G, obs, Cc, dtype=torch.float32, device=dd3.device) if want_state else None
+    if g_new4 is not None and not g_new4.is_contiguous():
+        g_new4 = g_new4.contiguous()
+    _check(lib().gcl_ar_step_bwd(_p(dd3), _p(g_loss), _p(g_new4), _pi(chan_kind), 1 if has_y else 0, 1 if residual else 0,
+                                 _p(d_delta), _p(d_state), B, G, obs, Cc, _stream()))
+    return d_delta, d_state
+
+
+def pad_rows(src3, rows_dst: int, F_dst: int):
+    """[B, r, F] (unit channel stride) -> zero-padded contiguous [B, rows_dst, F_dst] in one pass."""
+    B, r, F = src3.shape
+    assert src3.stride(2) == 1
+    dst = torch.empty(B, rows_dst, F_dst, dtype=torch.float32, device=src3.device)
+    _check(lib().gcl_pad_rows(_p(src3), src3.stride(1), src3.stride(0), r, F, _p(dst), F_dst, rows_dst * F_dst, rows_dst, F_dst,
+                              B, _stream()))
+    return dst
+
+
+def zero_(t: torch.Tensor):
+    """t.zero_() as a stream memset through the C ABI (no torch fill kernel on the step)."""
+    assert t.is_contiguous() and t.is_cuda
+    _check(lib().gcl_zero(t.data_ptr(), t.numel() * t.element_size(), _stream()))
+    return t
 
 
 def segment_reduce(src3, perm, rowptr, mean: bool, out3=None):
@@ -626,6 +653,8 @@ def gcn_layer_fwd(graph: Graph, x3, act, slope, W, bias, out=None):
     if out is None:
         out = torch.empty(B, n, Fst, dtype=torch.float32, device=x3.device)
     assert out.shape[2] >= Fst or out.stride(1) >= Fst
+    tok = _probe_begin("gcn_layer_fwd", graph=graph, B=B, Fin=Fin, Fout=Fout)
     _check(lib().gcl_gcn_layer_fwd(graph.handle, _p(x3), x3.stride(1), x3.stride(0), int(act), _p(slope), _p(W.contiguous()),
                                    _p(bias), _p(out), out.stride(1), out.stride(0), B, Fin, Fout, Fst, _stream()))
+    _probe_end(tok)
     return out[..., :Fout]

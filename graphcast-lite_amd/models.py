@@ -117,7 +117,7 @@ class GCNConv(nn.Module):
 
     def forward(self, x, edge_index):
         g = _graphs.get(edge_index, _num_nodes(x), hip.GRAPH_GCN)
-        return GCNStackFn.apply(x, self, g, 1, False, 1e-5, self.lin.weight, self.bias, None)
+        return GCNStackFn.apply(x, self, g, 1, False, 1e-5, 0, self.lin.weight, self.bias, None)
 
 
 class GATConv(nn.Module):
@@ -291,13 +291,13 @@ class InteractionNetProcessor(nn.Module):
         lay, raw, pad = self._edge_layout(edge_index, edge_attr_raw, _num_nodes(x), x.device)
         enc_W = self.edge_encoder[0].weight
         if pad:
-            raise NotImplementedError("edge_feature_dim must be a multiple of 4 on the HIP path")
+            # raw edge features are padded to 16-byte rows (zeros); the tiny [D, raw_dim] encoder weight gets matching
+            # zero columns (a differentiable pad of a few hundred floats, outside the per-edge work)
+            enc_W = torch.nn.functional.pad(enc_W, (0, pad))
         enc_act = self.edge_encoder[1]
         params = [enc_W, self.edge_encoder[0].bias, enc_act.weight if isinstance(enc_act, nn.PReLU) else None]
         for st in self.steps:
             params += st.step_params()
-        if self.const_slope is not None:
-            raise NotImplementedError("InteractionNet with ReLU is not on the HIP path (swish / prelu are)")
         eps = self.steps[0].node_norm.eps if self.use_layer_norm else 1e-5
         return InteractionNetFn.apply(x, self, lay, raw, len(self.steps), self.act_kind, self.use_layer_norm, eps, *params)
 
@@ -414,10 +414,12 @@ class GraphLayer(nn.Module):
             if fuse_ln:
                 params += [ln.weight, ln.bias]
             g = _graphs.get(edge_index, n, hip.GRAPH_GCN)
-            X = GCNStackFn.apply(X, self, g, len(convs), fuse_ln, ln.eps if fuse_ln else 1e-5, *params)
+            out_rows = int(kwargs.get("_out_rows") or 0)  # the caller keeps only the first rows (decoder: grid rows)
             if ln is not None and not fuse_ln:
+                X = GCNStackFn.apply(X, self, g, len(convs), False, 1e-5, 0, *params)
                 X = ln(X)
-            return X
+                return X[..., :out_rows, :] if out_rows else X
+            return GCNStackFn.apply(X, self, g, len(convs), fuse_ln, ln.eps if fuse_ln else 1e-5, out_rows, *params)
 
         if self.layer_type == GraphLayerType.GATConv:
             slope, act = None, hip.ACT_NONE
@@ -645,8 +647,9 @@ class WeatherPrediction(nn.Module):
             processed = self.processor.forward(X=mesh_lat, edge_index=self.processing_graph,
                                                attention_threshold=attention_threshold)
         dec_in = Gather2Fn.apply(enc_c, processed, c.maps_dec, G + c.U, B)          # [B, G+U, D]
-        decoded = self.decoder.forward(X=dec_in, edge_index=c.dec_graph)
-        out, grid_lat = decoded[:, :G, :], enc_c[:, :G, :]
+        gcn_dec = self.decoder.graph_layer.layer_type == GraphLayerType.ConvGCN
+        decoded = self.decoder.forward(X=dec_in, edge_index=c.dec_graph, **({"_out_rows": G} if gcn_dec else {}))
+        out, grid_lat = (decoded if gcn_dec else decoded[:, :G, :]), enc_c[:, :G, :]
         if squeeze:
             return out[0], grid_lat[0], processed[0]
         return out, grid_lat, processed
@@ -676,6 +679,9 @@ class WeatherPrediction(nn.Module):
             processed = self.processor.forward(
                 X=mesh_node_features, edge_index=self.processing_graph, attention_threshold=attention_threshold)
         processed_features = torch.cat((grid_node_features, processed), dim=-2)
+        if self.decoder.graph_layer.layer_type == GraphLayerType.ConvGCN:  # the row slice happens inside the stack
+            decoded = self.decoder.forward(X=processed_features, edge_index=self.decoding_graph, _out_rows=G)
+            return decoded, grid_node_features, processed
         decoded = self.decoder.forward(X=processed_features, edge_index=self.decoding_graph)
         return decoded[..., :G, :], grid_node_features, processed
 

@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 
 from . import hip
-from .functional import WeightedMSEFn
+from .functional import ARStepLossFn, WeightedMSEFn
 
 
 class FileNames:
@@ -133,10 +133,28 @@ def update_attention_threshold(epoch, max_epochs=30, start_epoch=5, final_thresh
     return min(final_threshold, (epoch - start_epoch) * final_threshold / (max_epochs - start_epoch))
 
 
+_kind_cache = {}
+
+
+def _channel_kinds(C, static_channels, forcing_channels, device):
+    """Device int32 [C] (0 predicted, 1 static, 2 forcing), cached: uploading it needs a host -> device copy that
+    must not happen on every step (nor inside a hipGraph capture)."""
+    from .predict import channel_kinds
+
+    key = (C, tuple(static_channels or ()), tuple(forcing_channels or ()), str(device))
+    k = _kind_cache.get(key)
+    if k is None:
+        k = _kind_cache[key] = channel_kinds(C, static_channels, forcing_channels, device)
+    return k
+
+
 def batch_loss(model, X, y, threshold=0.0, epoch=0, batch_num=1, lat_weights=None, current_ar_steps=1,
                channel_mask=None, spatial_mask=None, static_channels=None, forcing_channels=None,
                use_residual=True):
-    """Loss of one batch as the reference's inner loop builds it (src/train.py:173-231)."""
+    """Loss of one batch as the reference's inner loop builds it (src/train.py:173-231): per AR step the model
+    predicts a delta, the (residual) prediction is scored against that step's target, static / forcing channels are
+    overwritten and the window shifts; the step losses are averaged.  Each step is one `ARStepLossFn` (loss + window
+    advance fused, 1/steps folded into the loss normaliser, the running sum kept on the device)."""
     N, G, _ = X.shape
     obs = model.obs_window
     C = X.shape[-1] // obs
@@ -144,26 +162,17 @@ def batch_loss(model, X, y, threshold=0.0, epoch=0, batch_num=1, lat_weights=Non
     y_steps = y.view(N, G, steps_total, C)
     state = X.view(N, G, obs, C)
     steps = min(current_ar_steps, steps_total)
-    loss = 0
+    node_w, chan_w, wsum1 = _loss_weights(G, C, lat_weights, channel_mask, spatial_mask, X.device)
+    inv = 1.0 / (max(wsum1 * N, 1e-12) * steps)
+    kinds = _channel_kinds(C, static_channels, forcing_channels, X.device) if steps > 1 else None
+    loss = None
     for s in range(steps):
         delta = model(X=state.reshape(N, G, -1), attention_threshold=threshold, epoch=epoch, batch_num=batch_num)
         if delta.dim() == 2:
             delta = delta.unsqueeze(0)
-        x_last = state[:, :, -1, :]
-        target = y_steps[:, :, s, :]
-        loss = loss + weighted_mse_loss(delta, target, lat_weights, channel_mask, spatial_mask,
-                                        x_last=x_last if use_residual else None)
-        if s + 1 < steps:  # roll the window forward (src/train.py:215-228)
-            out = (x_last + delta) if use_residual else delta
-            out = out.clone()
-            if static_channels:
-                for ch in static_channels:
-                    out[:, :, ch] = x_last[:, :, ch]
-            if forcing_channels:
-                for ch in forcing_channels:
-                    out[:, :, ch] = target[:, :, ch]
-            state = torch.cat([state[:, :, 1:, :], out.unsqueeze(2)], dim=2)
-    return loss / steps
+        loss, state = ARStepLossFn.apply(state, delta, y_steps[:, :, s, :], loss, node_w, chan_w, inv, kinds,
+                                         bool(use_residual), s + 1 < steps)
+    return loss
 
 
 def train_epoch(model, train_dataloader, optimiser, loss_fn, device, threshold, epoch, lat_weights=None,
@@ -262,7 +271,10 @@ class FlatParams:
         self.num_params = sum(p.numel() for p in self.params)
 
     def zero_grad(self):
-        self.grad.zero_()
+        if self.grad.is_cuda:
+            hip.zero_(self.grad)  # stream memset through the C ABI (no torch fill kernel on the step)
+        else:
+            self.grad.zero_()     # (CPU buckets exist only in the gloo rehearsal tests of the sharding logic)
 
 
 def shard_batch(X, y, rank: int, world: int):

@@ -107,7 +107,9 @@ size_t gcl_linear_bwd_ws_bytes(int64_t rows, int32_t Fin, int32_t Fout);
 /* Whole backward of one dense transform in one call: dx (pre-activation gradient), dW, db (NULL: no
  * bias), the slope gradient, and optionally colsum_dx[c] (+)= sum_r dx[r,c] (the bias gradient of
  * the conv layer that produced x).  Uses ONE fused kernel (dY and x read once) when
- * Fout <= 64, Fin <= 96 and rows are 16-B aligned, else the three separate kernels.
+ * Fout <= 64, Fin <= 96 and rows are 16-B aligned, else the three separate kernels.  Fout itself need not be a
+ * multiple of 4 when lddy >= roundup(Fout, 4) and the padding columns of dy hold finite values (zeros): this is how
+ * the 33- / 19-wide last decoder conv runs on 16-byte rows without padded copies of its weight.
  * `accumulate` is a bit mask with ONE BIT PER DESTINATION (they belong to different parameters,
  * whose gradients may be in different states): a set bit adds into that destination, a clear bit
  * overwrites it.  *d_in_slope is always added to. */
@@ -237,11 +239,13 @@ int gcl_assemble_input(const float* x /*[B,G,Cdyn]*/, const float* grid_static /
  * x_last / y are addressed as base + b*bs + g*ld + c.  loss_out: one device float (overwritten).
  * out_state (may be NULL) receives `out` for autoregressive roll-forward.
  * ------------------------------------------------------------------------------------------- */
+/* loss_prev (device float, may be NULL): *loss_out = *loss_prev + loss of this call - the running sum over the
+ * autoregressive steps of one batch (src/train.py:213,231) without a separate add. */
 int gcl_wmse_fwd_bwd(const float* delta, int64_t ldd, int64_t bsd, const float* x_last, int64_t ldx,
                      int64_t bsx, const float* y, int64_t ldy_, int64_t bsy, const float* node_w,
                      const float* chan_w, float inv_wsum, float grad_scale, float* d_delta,
-                     float* out_state, float* loss_out, int32_t B, int32_t G, int32_t C,
-                     void* ws, size_t ws_bytes, gcl_stream_t stream);
+                     float* out_state, const float* loss_prev, float* loss_out, int32_t B, int32_t G,
+                     int32_t C, void* ws, size_t ws_bytes, gcl_stream_t stream);
 size_t gcl_wmse_ws_bytes(int32_t B, int32_t G, int32_t C);
 
 /* torch.optim.Adam step (src/main.py:212, src/train.py:233) over one flat parameter buffer:
@@ -316,10 +320,27 @@ int gcl_window_pack(const uint16_t* series /* IEEE binary16 */, int64_t T, int32
  * step_out is appended to `out` at column out_off (out may be NULL) and the window
  * state [B,G,obs,C] is shifted by one step into new_state (must not alias state).
  * state / delta / new_state are contiguous; y_step and out are addressed with (ld, bs). */
-int gcl_ar_advance(const float* state, const float* delta, const float* y_step, int64_t ldy, int64_t bsy,
-                   const int32_t* chan_kind, float* new_state, float* out, int64_t ldo, int64_t bso,
-                   int32_t out_off, int32_t B, int32_t G, int32_t obs, int32_t C, int32_t residual,
-                   gcl_stream_t stream);
+int gcl_ar_advance(const float* state, const float* delta, int64_t ldd, int64_t bsd, const float* y_step,
+                   int64_t ldy, int64_t bsy, const int32_t* chan_kind, float* new_state, float* out,
+                   int64_t ldo, int64_t bso, int32_t out_off, int32_t B, int32_t G, int32_t obs, int32_t C,
+                   int32_t residual, gcl_stream_t stream);
+/* Backward of one autoregressive TRAINING step = gcl_wmse_fwd_bwd (loss of the step, dd = d loss / d pred for a unit
+ * upstream gradient) + gcl_ar_advance (src/train.py:203-228), in one pass:
+ *   d_delta = g_loss dd + [predicted channel] g_new[last slot]
+ *   d_state = shift(g_new) + last slot: [residual] g_loss dd + [static, or predicted with residual] g_new[last slot]
+ * g_loss: device float (upstream gradient of the loss sum), g_new: gradient of the advanced window [B,G,obs,C] or NULL
+ * (last step), d_state may be NULL (the first window is data).  All tensors contiguous. */
+int gcl_ar_step_bwd(const float* dd, const float* g_loss, const float* g_new, const int32_t* chan_kind,
+                    int32_t has_y, int32_t residual, float* d_delta, float* d_state, int32_t B, int32_t G,
+                    int32_t obs, int32_t C, gcl_stream_t stream);
+
+/* dst[b, i, c] = (i < rows_src && c < F_src) ? src[b, i, c] : 0 for i < rows_dst, c < F_dst: the gradient of a row /
+ * column slice (decoder output: grid rows, first 33 / 19 columns - src/models.py:870-872) widened to the sliced
+ * tensor's zero-padded layout, in one pass. */
+int gcl_pad_rows(const float* src, int64_t lds, int64_t bss, int32_t rows_src, int32_t F_src, float* dst,
+                 int64_t ldd, int64_t bsd, int32_t rows_dst, int32_t F_dst, int32_t B, gcl_stream_t stream);
+/* hipMemsetAsync(ptr, 0, nbytes) on the stream (optimizer.zero_grad of the flat gradient bucket, src/train.py:166). */
+int gcl_zero(void* ptr, size_t nbytes, gcl_stream_t stream);
 
 /* Row gather from up to two sources (stage glue of src/models.py:837-838,860-862 restricted to the
  * rows that matter):  dst[b,i,:] = a[b, map_a[i], :] if map_a[i] >= 0 (map_a NULL = identity), else

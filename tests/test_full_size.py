@@ -8,21 +8,11 @@ import pytest
 import torch
 
 from oracle import train_step as T
+from parity import check_grads, grads_of, oracle_fp64
 from test_hip_model import DEV, data, make_pair, rel
 
 pytestmark = pytest.mark.gpu
 NLAT, NLON = 256, 512
-
-
-def _grad_check(m, o, tol=1e-4):
-    og = dict(o.named_parameters())
-    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in og.values() if p.grad is not None)))
-    for n_, p in m.named_parameters():
-        if og[n_].grad is None:
-            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, n_
-            continue
-        d = float((p.grad.double().cpu() - og[n_].grad.double()).norm())
-        assert d <= tol * float(og[n_].grad.double().norm()) + 1e-6 * gn, (n_, d)
 
 
 @pytest.mark.parametrize("name", ["wb2_512x256_19f_ar", "wb2_512x256_sparse_gat"])
@@ -32,16 +22,21 @@ def test_full_size_forward_backward_parity(name):
     cfg, m, o = make_pair(name, None, nlat=NLAT, nlon=NLON)
     assert (m._num_grid_nodes, m._num_mesh_nodes) == (131072, 40962)
     assert int(m.processing_graph.shape[1]) == 261120 and int(m.decoding_graph.shape[1]) == 393216
-    X, y = data(cfg, m._num_grid_nodes, 2)
+    B = 8  # BASELINE.json configs[3] / [4]: batch 8 per GPU
+    X, y = data(cfg, m._num_grid_nodes, B)
     out_h = m(X.to(DEV))
-    assert rel(out_h[:1], o(X[:1]).unsqueeze(0)) < 1e-5
-    # a batch is its samples (size-independent property; also covers sample 1 without a second oracle pass)
-    assert rel(out_h[1], m(X[1:].to(DEV))) < 1e-6
+    for i in (0, B - 1):  # oracle on the first and last sample of the batch
+        assert rel(out_h[i], o(X[i:i + 1])) < 1e-5, i
+    # a batch is its samples (size-independent property: covers every sample without more oracle passes)
+    for i in range(B):
+        assert rel(out_h[i], m(X[i:i + 1].to(DEV))) < 1e-6, i
     lw = T.get_lat_weights(NLAT, NLON)
-    T.train_step_loss(o, X[:1], y[:1], lat_weights=lw).backward()
-    loss_h = batch_loss(m, X[:1].to(DEV), y[:1].to(DEV), lat_weights=get_lat_weights(NLAT, NLON, DEV))
+    T.train_step_loss(o, X[:2], y[:2], lat_weights=lw).backward()
+    loss_h = batch_loss(m, X[:2].to(DEV), y[:2].to(DEV), lat_weights=get_lat_weights(NLAT, NLON, DEV))
     loss_h.backward()
-    _grad_check(m, o)
+    o64 = oracle_fp64(o)
+    T.train_step_loss(o64, X[:2].double(), y[:2].double(), lat_weights=lw.double()).backward()
+    check_grads(grads_of(m), grads_of(o), grads_of(o64), tag=f"full size {name}")
     if name == "wb2_512x256_sparse_gat":  # pruning at full size: same kept edges as the oracle's threshold rule
         thr = 0.15
         _, new_h = m.processor(m.encoder(m._preprocess_input(X[0].to(DEV)), m.encoding_graph)[m._num_grid_nodes:],
@@ -53,17 +48,30 @@ def test_full_size_forward_backward_parity(name):
         assert abs(new_h.shape[1] - new_o.shape[1]) <= max(4, int(1e-4 * new_o.shape[1]))
 
 
-def test_full_size_interaction_net_forward():
-    """wb2_512x256_19f_ar_v2 at full size: forward against the oracle (its backward alone is ~20 s of CPU),
-    backward runs and gives finite, non-zero gradients for every step's weights."""
+def test_full_size_interaction_net_forward_backward():
+    """wb2_512x256_19f_ar_v2 at full size: forward against the oracle, and the backward of the whole 12-step
+    processor against the oracle's autograd (fp32, ~30 s of CPU) for EVERY parameter: the last two message-passing
+    steps' weights at the 1e-5 bar + twice-the-reference-error rule is out of reach without a float64 pass at this
+    size (a float64 oracle backward needs ~40 GB), so the bound here is 1e-4 relative per parameter with the
+    module-local 1e-6 floor of tests/parity.py - tighter than round 1's finite / non-zero check by four orders."""
     cfg, m, o = make_pair("wb2_512x256_19f_ar_v2", None, nlat=NLAT, nlon=NLON)
     X, y = data(cfg, m._num_grid_nodes, 1)
-    with torch.no_grad():
-        want = o(X)
+    want = o(X)
     got = m(X.to(DEV))
     assert rel(got, want) < 1e-5
     (got - y[0].to(DEV)).pow(2).mean().backward()
+    (want - y[0]).pow(2).mean().backward()
+    og = {k: p.grad for k, p in o.named_parameters()}
+    worst = ("", 0.0)
     for n_, p in m.named_parameters():
         if "steps.11.edge_norm" in n_:  # the last step's edge state is never read (src/models.py:282-285)
             continue
         assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0, n_
+        mk = n_.rsplit(".", 1)[0]
+        floor = 1e-6 * max(float(g.double().norm()) for k, g in og.items() if g is not None and k.startswith(mk))
+        ref = og[n_].double()
+        d = float((p.grad.double().cpu() - ref).norm())
+        if d / (float(ref.norm()) + 1e-300) > worst[1]:
+            worst = (n_, d / (float(ref.norm()) + 1e-300))
+        assert d <= 1e-4 * float(ref.norm()) + floor, (n_, d, float(ref.norm()))
+    print(f"v2 full-size backward: worst relative gradient error {worst[1]:.2e} ({worst[0]})")
