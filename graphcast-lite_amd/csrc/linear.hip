@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "x3.h"
 
 namespace {
 
@@ -1294,6 +1295,9 @@ extern "C" int gcl_dense_fwd(const float* x, int64_t ldx, int32_t act, const flo
                 (long long)ldy, (long long)ldw);
   if (int rc = check_act("dense_fwd", act, slope)) return rc;
   const bool vec_x = (Fin % 4 == 0) && (ldx % 4 == 0) && gcl::aligned16(x);
+  if (!addend && ldw == Fin && !use_valu() && gcl::x3_linear_fwd_applicable(x, ldx, y, ldy, Fin, Fout, act))
+    return gcl::x3_linear_fwd(x, ldx, act, act == GCL_ACT_PRELU ? slope : nullptr, W, bias, y, ldy, rows, Fin, Fout,
+                              (hipStream_t)stream);
   if (!addend && ldw == Fin && (use_valu() || panel_fits(Fin, Fout, vec_x, false, (ldw % 4 == 0) && gcl::aligned16(W))))
     return launch_linear<EPI_BIAS>(x, ldx, act == GCL_ACT_PRELU ? slope : nullptr, W, Fin, 0, bias, y, ldy, rows, Fin,
                                    Fout, nullptr, 0, nullptr, nullptr, nullptr, (hipStream_t)stream, act);
@@ -1528,16 +1532,22 @@ extern "C" int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W,
   const int FoP = NO * 32, FiP = NC * 32;
   static const int no64 = [] { const char* e = getenv("GCL_NO_FUSED64"); return (e && atoi(e)) ? 1 : 0; }();
   const bool use64 = (NC == 2) && !no64;  // 64-row tiles, 3 blocks per CU
+  // split-operand bf16 kernel (x3.h): same partial records, two blocks per CU
+  const bool use_x3 = use64 && gcl::x3_linear_bwd_applicable(dy, lddy, x, ldx, dx, lddx, Fin, Fout);
   const int64_t ntiles = gcl::cdiv(rows, use64 ? 64 : 128);
   const int64_t cap = use64 ? 3 * gcl::kNumCU : gcl::kNumCU;
-  const int nblk = (int)(ntiles < cap ? ntiles : cap);
+  const int nblk = use_x3 ? gcl::x3_linear_bwd_blocks(rows) : (int)(ntiles < cap ? ntiles : cap);
   const size_t rec_f = (size_t)FoP * FiP + FoP + FiP;  // floats per block record
   float* part_dw = (float*)ws;
   float* part_db = part_dw + (size_t)FoP * FiP;
   float* part_cs = part_db + FoP;
   double* part_sl = (double*)(((uintptr_t)(part_dw + (size_t)3 * gcl::kNumCU * rec_f) + 15) & ~(uintptr_t)15);
   const bool want_slope = in_slope && d_in_slope;
-  if (use64) {
+  if (use_x3) {
+    if (int rc = gcl::x3_linear_bwd(dy, lddy, W, x, ldx, in_slope, dx, lddx, rows, Fin, Fout, part_dw, db ? part_db : nullptr,
+                                    colsum_dx ? part_cs : nullptr, want_slope ? part_sl : nullptr, st))
+      return rc;
+  } else if (use64) {
     const size_t lds64 = ((size_t)FiP * (FoP + 2) + 64 * (size_t)(FoP + 2) + 64 * (size_t)FiP) * sizeof(float);
 #define GCL_FB64(NO_)                                                                                             \
   do {                                                                                                            \

@@ -4,6 +4,7 @@
 // Build: hipcc -O3 --offload-arch=gfx950 tools/probes/mfma_valu_probe.hip -o /tmp/probe && /tmp/probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -68,6 +69,63 @@ __global__ __launch_bounds__(512, 2) void probe(float* out, int mode, int iters,
   if ((threadIdx.x & 63) == 0) reinterpret_cast<unsigned long long*>(out)[256 + blockIdx.x * 8 + wave] = t_end - t_begin;
 }
 
+// Interleaved stream of ONE wave: every MFMA is followed by NV independent v_fma_f32 of the same wave (the guide's
+// "fillers in the MFMA gap").  WPS waves per SIMD run the same stream.
+template <int KIND, int NV, int WPS>
+__global__ __launch_bounds__(256 * WPS) void probe_il(float* out, int iters) {
+  f32x16 a0 = {0}, a1 = {0};
+  float x = threadIdx.x * 1e-3f, y = 1.0001f;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = x + i;
+  bf16x8 p = {(short)threadIdx.x, 1, 2, 3, 4, 5, 6, 7}, q = {7, 6, 5, 4, 3, 2, 1, (short)threadIdx.x};
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (KIND == 0) {
+        if (k & 1) a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a1, 0, 0, 0);
+        else a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a0, 0, 0, 0);
+      } else {
+        if (k & 1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p, q, a1, 0, 0, 0);
+        else a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q, p, a0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < NV; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[j & 7]) : "v"(y), "v"(x));
+    }
+  }
+  const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+  float s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += v[i];
+  for (int r = 0; r < 16; ++r) s += a0[r] + a1[r];
+  if (s == 12345.678f) out[threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) reinterpret_cast<unsigned long long*>(out)[256 + blockIdx.x * 16 + (threadIdx.x >> 6)] = t_end - t_begin;
+}
+
+template <int KIND, int NV, int WPS>
+void run_il(const char* name) {
+  float* out;
+  hipMalloc(&out, 1 << 20);
+  static unsigned long long host[256 * 16];
+  const int iters = 400;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((probe_il<KIND, NV, WPS>), dim3(256), dim3(256 * WPS), 0, 0, out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+  }
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  hipMemcpy(host, reinterpret_cast<unsigned long long*>(out) + 256, sizeof(host), hipMemcpyDeviceToHost);
+  unsigned long long mx = 0;
+  for (int i = 0; i < 256 * 16; ++i) if ((i & 15) < 4 * WPS) mx = host[i] > mx ? host[i] : mx;
+  printf("%s + %2d v_fma per MFMA, %d wave(s)/SIMD: %.1f cycles of SIMD time per MFMA (%.1f us)\n", name, NV, WPS,
+         (double)mx / (iters * 16.0 * WPS), ms * 1e3);
+  hipFree(out);
+}
+
 template <int KIND, int NOPS = 0>
 void run(const char* name, int nm = 64) {
   float* out;
@@ -93,6 +151,12 @@ void run(const char* name, int nm = 64) {
   }
 }
 int main() {
+  run_il<0, 0, 1>("f32_32x32x2 "); run_il<0, 4, 1>("f32_32x32x2 "); run_il<0, 8, 1>("f32_32x32x2 ");
+  run_il<0, 12, 1>("f32_32x32x2 "); run_il<0, 14, 1>("f32_32x32x2 "); run_il<0, 16, 1>("f32_32x32x2 "); run_il<0, 24, 1>("f32_32x32x2 ");
+  run_il<0, 0, 2>("f32_32x32x2 "); run_il<0, 8, 2>("f32_32x32x2 "); run_il<0, 12, 2>("f32_32x32x2 "); run_il<0, 16, 2>("f32_32x32x2 ");
+  run_il<2, 0, 1>("bf16_32x32x16"); run_il<2, 4, 1>("bf16_32x32x16"); run_il<2, 6, 1>("bf16_32x32x16"); run_il<2, 8, 1>("bf16_32x32x16");
+  run_il<2, 4, 2>("bf16_32x32x16"); run_il<2, 6, 2>("bf16_32x32x16"); run_il<2, 8, 2>("bf16_32x32x16");
+  if (getenv("PROBE_IL_ONLY")) return 0;
   run<0>("mfma_f32_32x32x2 ");
   run<0, 10>("mfma_f32_32x32x2 + s_nop 9 ", 64);
   run<0, 12>("mfma_f32_32x32x2 + s_nop 11", 64);
