@@ -389,7 +389,14 @@ __global__ __launch_bounds__(256, 2) void linear_x3_bwd_kernel(
   float4 cur_p[4];
 
   issue(blockIdx.x);
+#ifdef GCL_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#endif
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+#ifdef GCL_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    X3_STAMP(0);
     // ---- split this thread's rows into the images ----
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -413,8 +420,11 @@ __global__ __launch_bounds__(256, 2) void linear_x3_bwd_kernel(
       *reinterpret_cast<u32x2*>(Pimg + off + kImg64B) = u32x2{a01.m, a23.m};
       *reinterpret_cast<u32x2*>(Pimg + off + 2 * kImg64B) = u32x2{a01.l, a23.l};
     }
+    X3_STAMP(1);
     __syncthreads();
+    X3_STAMP(2);
     issue(t + gridDim.x);
+    X3_STAMP(3);
 
     // ---- dX block (rows 32rg.., columns 32sg..), smallest piece products first ----
     {
@@ -441,6 +451,7 @@ __global__ __launch_bounds__(256, 2) void linear_x3_bwd_kernel(
       for (int r = 0; r < 16; ++r) Stg[(rg * 32 + d_row(r, lane)) * 64 + sg * 32 + li] = acc[r];
     }
 
+    X3_STAMP(4);
     // ---- dW block (so, sc) over the 64 rows of the tile: both operands by transposing reads ----
     if (has_tile) {  // wave-uniform
       const unsigned char* ya = Yimg + tro + so * 64;
@@ -455,7 +466,12 @@ __global__ __launch_bounds__(256, 2) void linear_x3_bwd_kernel(
         dw_hi = mfma_hi(dw_hi, ah, bh);
       }
     }
+#ifdef GCL_STAMPS
+    asm volatile("" ::"v"(dw_hi[0]), "v"(dw_lo[0]));
+#endif
+    X3_STAMP(5);
     __syncthreads();
+    X3_STAMP(6);
 
     // ---- finish dX: the thread that loaded P[row, 4 columns] owns that float4 of the result ----
     {
@@ -475,7 +491,12 @@ __global__ __launch_bounds__(256, 2) void linear_x3_bwd_kernel(
         buf_st4(rx, pok ? (unsigned)((row * lddx + csub * 4) * 4) : kOOB, v);
       }
     }
+    X3_STAMP(7);
   }
+#ifdef GCL_STAMPS
+  if (lane == 0 && blockIdx.x < 1024)
+    for (int i = 0; i < 8; ++i) x3_stamps[(blockIdx.x * 4 + wave) * 8 + i] = stamp_acc[i];
+#endif
 
   // ---- per-block partials ----
   constexpr size_t REC = (size_t)FoP * FiP + FoP + FiP;

@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--config", default="baseline")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--only", default="", help="comma list of: copy,linear,agg,gcn,norm,misc (default all)")
+    ap.add_argument("--only", default="", help="comma list of: copy,linear,agg,gcn,gat,norm,misc (default all but gat)")
     ap.add_argument("--rcb", type=int, default=0, help="renumber the mesh nodes by recursive coordinate bisection "
                     "with leaves of this many nodes (locality experiment; 0 = reference order)")
     args = ap.parse_args()
@@ -123,6 +123,22 @@ def main():
         for act, an in ((hip.ACT_NONE, "none"), (hip.ACT_PRELU, "prelu")):
             us, mn = timeit(lambda: hip.gcn_layer_fwd(gr, x, act, slope if act else None, W, bias, out=out), args.iters)
             row(f"gcn_layer_fwd {tag} act={an} F={F}", us, mn, B * per, 2 * B * nn_ * F * F + 2 * B * gr.e * F)
+
+    # GATConv / SparseGATConv attention aggregation on the mesh graph (H = 1 head of C = F channels, as configs[2]/[4])
+    if "gat" in only:
+        H, C = 1, F
+        gr = _graphs.get(m.processing_graph, M, hip.GRAPH_GAT)
+        h = rnd(B, M, H * C)
+        a_s, a_d, bias = rnd(H * C) * 0.3, rnd(H * C) * 0.3, rnd(C)
+        # per sample: read h at every edge end is served from cache; algorithmic = h once + y once + alpha + indices
+        per = 4 * M * (H * C + C) + 4 * gr.e * H + 4 * gr.e + 4 * (M + 1)
+        us, mn = timeit(lambda: hip.gat_fwd(gr, h, a_s, a_d, bias, H, C), args.iters)
+        row(f"gat_fwd mesh n={M} E'={gr.e} H={H} C={C}", us, mn, B * per, 2 * B * gr.e * H * C * 2)
+        y, s_src, s_dst, alpha = hip.gat_fwd(gr, h, a_s, a_d, bias, H, C)
+        dy = rnd(B, M, C)
+        d_as, d_ad, d_b = torch.empty(H * C, device=dev), torch.empty(H * C, device=dev), torch.empty(C, device=dev)
+        us, mn = timeit(lambda: hip.gat_bwd(gr, dy, h, a_s, a_d, s_src, s_dst, alpha, d_as, d_ad, d_b, False, H, C), args.iters)
+        row(f"gat_bwd mesh (dh, d_att, d_bias)", us, mn, B * (per + 4 * M * H * C + 4 * M * C), 2 * B * gr.e * H * C * 4)
 
     if "norm" not in only:
         return

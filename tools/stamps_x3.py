@@ -28,8 +28,17 @@ print(f"cycles per wave (median) {np.median(tot):.0f} over {(rows + 127) // 128 
       + ", ".join(f"{nm} {st[:, i].sum() / tot.sum():.2f}" for i, nm in enumerate(names)))
 print("   per-phase median cycles per wave:", [int(np.median(st[:, i])) for i in range(6)])
 print("   set-up cycles per wave (median / max):", int(np.median(st[:, 6])), int(st[:, 6].max()))
-t0 = st[:, 7] - st[:, 7].min()
-end = t0 + st[:, 6] + tot
-print("   wave start offsets (cycles): median %d, 90%% %d, max %d;  last wave ends at %d" % (np.median(t0), np.percentile(t0, 90), t0.max(), end.max()))
-blk = t0.reshape(-1, 4)[:, 0]
-print("   block start offsets by block index (every 32nd):", [int(v) for v in blk[::32]])
+
+# fused backward, same shape
+dy, P = torch.randn(rows, F, device=dev), torch.randn(rows, F, device=dev)
+dW, db, cs, da = torch.empty(F, F, device=dev), torch.empty(F, device=dev), torch.empty(F, device=dev), torch.zeros(1, device=dev)
+for _ in range(3):
+    hip.linear_bwd_all(dy, W, P, sl, da, dW, db, cs, False)
+torch.cuda.synchronize()
+assert L.gcl_debug_read_stamps_x3(buf.ctypes.data, buf.size) == 0
+st = buf.reshape(-1, 8)[:512 * 4].astype(np.float64)
+names = ["wait loads", "split+commit", "barrier 1", "issue", "dX mfma+stage", "dW mfma", "barrier 2", "finish+store"]
+tot = st.sum(axis=1)
+print(f"backward: cycles per wave (median) {np.median(tot):.0f} over {(rows + 63) // 64 / 512:.1f} tiles; shares: "
+      + ", ".join(f"{nm} {st[:, i].sum() / tot.sum():.2f}" for i, nm in enumerate(names)))
+print("   per-phase median cycles per wave:", [int(np.median(st[:, i])) for i in range(8)])
