@@ -370,18 +370,18 @@ class AssembleFn(torch.autograd.Function):
     """`_preprocess_input` (src/models.py:776-806)."""
 
     @staticmethod
-    def forward(ctx, x, grid_static, mesh_static):
+    def forward(ctx, x, grid_static, mesh_static, tail3=None):
         squeeze = x.dim() == 2
         x3 = _flat3(x.detach())
         ctx.squeeze, ctx.G, ctx.Cdyn = squeeze, x3.shape[1], x3.shape[2]
-        out = hip.assemble_input(x3, grid_static, mesh_static)
+        out = hip.assemble_input(x3, grid_static, mesh_static, tail3)
         return out[0] if squeeze else out
 
     @staticmethod
     def backward(ctx, dy):
         dy3 = dy if dy.dim() == 3 else dy.unsqueeze(0)
         dx = dy3[:, : ctx.G, : ctx.Cdyn].contiguous()
-        return (dx[0] if ctx.squeeze else dx), None, None
+        return (dx[0] if ctx.squeeze else dx), None, None, None
 
 
 class WeightedMSEFn(torch.autograd.Function):
@@ -467,6 +467,38 @@ class Gather2Fn(torch.autograd.Function):
             bc = ctx.sb[0] == 1 and ctx.B > 1
             db = hip.gather2_rows(g, inv_b, None, None, ctx.sb[1], ctx.B, sum_batch=bc)
         return da, db, None, None, None
+
+
+class MeshLatFn(torch.autograd.Function):
+    """Mesh latents [B, M, D] of the compact pipeline from ONE encoder output [B, n_e, D] whose rows per sample are
+    [G grid | Md batch-dependent mesh | r folded batch-invariant mesh rows]: the Mi batch-invariant mesh rows are
+    dealt r = ceil(Mi / B) to a sample as isolated nodes, so they ride through the encoder's launches instead of a
+    second (B = 1) pass of small launches.  Mesh row i reads enc[b, map_a[i]] (dependent rows) or the flat row
+    map_b[i] of enc viewed as [1, B * n_e, D] (folded rows, shared by all samples).
+    Backward: rows < G + Md gather g[b, inv_a[j]] (grid rows: 0), folded row j of the flat list gets the batch sum
+    of g[:, inv_fold[j]]."""
+
+    @staticmethod
+    def forward(ctx, enc, maps, M: int, gmd: int, r: int):
+        map_a, map_b, inv_a, inv_fold = maps
+        e3 = enc.detach()
+        if not e3.is_contiguous():
+            e3 = e3.contiguous()
+        B, ne, D = e3.shape
+        ctx.maps, ctx.shape, ctx.gmd, ctx.r = maps, (B, ne, D), gmd, r
+        return hip.gather2_rows(e3, map_a, e3.view(1, B * ne, D), map_b, M, B)
+
+    @staticmethod
+    def backward(ctx, g):
+        _, _, inv_a, inv_fold = ctx.maps
+        B, ne, D = ctx.shape
+        g = g.contiguous()
+        out = torch.empty(B, ne, D, dtype=torch.float32, device=g.device)
+        hip.gather2_rows(g, inv_a, None, None, ctx.gmd, B, out=out[:, : ctx.gmd])
+        if ctx.r > 0:
+            tmp = hip.gather2_rows(g, inv_fold, None, None, B * ctx.r, B, sum_batch=True)
+            hip.copy_rows(tmp.view(B, ctx.r, D), out[:, ctx.gmd:])
+        return out, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------

@@ -460,12 +460,16 @@ def gat_prune(graph: Graph, alpha_edges, threshold: float) -> torch.Tensor:
     return buf[: 2 * k].view(2, k).clone()
 
 
-def assemble_input(x3, grid_static, mesh_static):
+def assemble_input(x3, grid_static, mesh_static, tail3=None):
+    """[B, G + M, Cdyn + Cs] = grid rows [x | grid_static], mesh rows [0 | mesh_static]; `tail3` [B, r, C] (optional)
+    overwrites the last r mesh rows of every sample (per-sample rows: the folded batch-invariant mesh rows)."""
     B, G, Cdyn = x3.shape
     M, Cs = mesh_static.shape
     x3 = x3.contiguous()
     out = torch.empty(B, G + M, Cdyn + Cs, dtype=torch.float32, device=x3.device)
     _check(lib().gcl_assemble_input(_p(x3), _p(grid_static), _p(mesh_static), _p(out), Cdyn + Cs, B, G, M, Cdyn, Cs, _stream()))
+    if tail3 is not None:
+        copy_rows(tail3, out[:, G + M - tail3.shape[1]:, :])
     return out
 
 
@@ -513,15 +517,18 @@ def _pi(t):
     return t.data_ptr()
 
 
-def gather2_rows(a3, map_a, b3, map_b, nd: int, B: int, sum_batch: bool = False):
+def gather2_rows(a3, map_a, b3, map_b, nd: int, B: int, sum_batch: bool = False, out=None):
     """dst[b,i] = a3[b, map_a[i]] | b3[b or 0, map_b[i]] | 0   (see gcl_gather2_rows).
-    a3 / b3: [Ba, na, F] with unit channel stride; Ba == 1 broadcasts over B."""
+    a3 / b3: [Ba, na, F] with unit channel stride; Ba == 1 broadcasts over B.  `out`: a (possibly row-strided)
+    [B | 1, nd, F] destination, e.g. a row range of a larger buffer."""
     F = a3.shape[-1]
-    out = torch.empty(1 if sum_batch else B, nd, F, dtype=torch.float32, device=a3.device)
+    if out is None:
+        out = torch.empty(1 if sum_batch else B, nd, F, dtype=torch.float32, device=a3.device)
+    assert out.shape == (1 if sum_batch else B, nd, F) and out.stride(2) == 1
     bsa = a3.stride(0) if (a3.shape[0] > 1 or sum_batch) else 0
     bsb = 0 if b3 is None else (b3.stride(0) if b3.shape[0] > 1 else 0)
     _check(lib().gcl_gather2_rows(_p(a3), a3.stride(1), bsa, _pi(map_a), _p(b3), 0 if b3 is None else b3.stride(1),
-                                  bsb, _pi(map_b), _p(out), F, nd * F, B, nd, F, 1 if sum_batch else 0, _stream()))
+                                  bsb, _pi(map_b), _p(out), out.stride(1), out.stride(0), B, nd, F, 1 if sum_batch else 0, _stream()))
     return out
 
 

@@ -41,7 +41,7 @@ from .config import (
 from .create_graphs import (create_decoding_graph, create_encoding_graph, create_processing_graph,
                             create_product_graph)
 from .functional import (AssembleFn, EdgeLayout, GATLayerFn, Gather2Fn, GCNStackFn, GraphNormFn, InteractionNetFn,
-                         LayerNormFn, MeanAggFn, MLPFn)
+                         LayerNormFn, MeanAggFn, MeshLatFn, MLPFn)
 from .mesh import get_hierarchy_of_triangular_meshes_for_sphere, get_mesh_lat_long, prune_mesh_to_region
 
 
@@ -620,8 +620,40 @@ class WeatherPrediction(nn.Module):
         dinv_b = torch.full((M,), -1, dtype=torch.int64)
         dinv_b[used] = G + torch.arange(U)
         c.maps_dec = (i32(dmap_a), i32(dmap_b), i32(dinv_a), i32(dinv_b))
+        c.fold = {}
+        c.mi = mi
         self._compact = c
         return c
+
+    _fold_invariant_rows = os.environ.get("GCL_NO_FOLD", "0") in ("0", "")
+
+    def _fold_setup(self, c, B: int, device):
+        """Per batch size: r = ceil(Mi / B) batch-invariant mesh rows are appended to every sample of the compact
+        encoder input as isolated nodes (GCNConv gives them their self-loop with weight 1, so each still sees only
+        its own `[0 | static]` input - src/models.py:792-801), flat row j of that list sits in sample j // r."""
+        G, M, Md, Mi = self._num_grid_nodes, self._num_mesh_nodes, c.Md, c.Mi
+        r = -(-Mi // B)
+        ne = G + Md + r
+        Cs, Cdyn = self.init_mesh_features.shape[1], self._dyn_size
+        f = type("Fold", (), {})()
+        f.r, f.ne = r, ne
+        stat = self.init_mesh_features.to(device)
+        f.mstat = torch.cat([c.mstat_dep.to(device), torch.zeros(r, Cs, device=device)], dim=0).contiguous()
+        x_fold = torch.zeros(B * r, Cdyn + Cs, device=device)
+        x_fold[:Mi, Cdyn:] = stat[c.mi.to(device)]
+        f.x_fold = x_fold.view(B, r, Cdyn + Cs)
+        i32 = lambda t: t.to(torch.int32).contiguous().to(device)
+        j = torch.arange(Mi)
+        map_b = torch.full((M,), -1, dtype=torch.int64)
+        map_b[c.mi] = (j // r) * ne + G + Md + (j % r)
+        inv_fold = torch.full((B * r,), -1, dtype=torch.int64)
+        inv_fold[:Mi] = c.mi
+        f.maps = (c.maps_mesh[0], i32(map_b), c.maps_mesh[2], i32(inv_fold))
+        # decoder-input maps: the encoder output now has ne rows per sample, the folded ones feed nothing there
+        dinv_a = torch.cat([c.maps_dec[2], torch.full((r,), -1, dtype=torch.int32, device=device)]).contiguous()
+        f.maps_dec = (c.maps_dec[0], c.maps_dec[1], dinv_a, c.maps_dec[3])
+        c.fold[B] = f
+        return f
 
     def _forward_compact(self, X: torch.Tensor, attention_threshold=0.0, **kwargs):
         G, M = self._num_grid_nodes, self._num_mesh_nodes
@@ -631,10 +663,19 @@ class WeatherPrediction(nn.Module):
         if self.use_product_graph:
             X3 = self._product_stage(X3)
         c = getattr(self, "_compact", None) or self._compact_setup(X3.device)
-        x_c = AssembleFn.apply(X3, self.init_grid_features, c.mstat_dep)           # [B, G+Md, C]
-        enc_c = self.encoder.forward(X=x_c, edge_index=c.enc_graph)                 # [B, G+Md, D]
-        inv = self.encoder.forward(X=c.x_inv, edge_index=c.empty_graph) if c.Mi > 0 else None  # [1, Mi, D]
-        mesh_lat = Gather2Fn.apply(enc_c, inv, c.maps_mesh, M, B)                   # [B, M, D]
+        if c.Mi > 0 and self._fold_invariant_rows:
+            # the Mi batch-invariant mesh rows ride through the SAME launches as r isolated nodes per sample
+            f = c.fold.get(B) or self._fold_setup(c, B, X3.device)
+            x_c = AssembleFn.apply(X3, self.init_grid_features, f.mstat, f.x_fold)  # [B, G+Md+r, C]
+            enc_c = self.encoder.forward(X=x_c, edge_index=c.enc_graph)             # [B, G+Md+r, D]
+            mesh_lat = MeshLatFn.apply(enc_c, f.maps, M, G + c.Md, f.r)             # [B, M, D]
+            maps_dec = f.maps_dec
+        else:
+            maps_dec = c.maps_dec
+            x_c = AssembleFn.apply(X3, self.init_grid_features, c.mstat_dep)           # [B, G+Md, C]
+            enc_c = self.encoder.forward(X=x_c, edge_index=c.enc_graph)                 # [B, G+Md, D]
+            inv = self.encoder.forward(X=c.x_inv, edge_index=c.empty_graph) if c.Mi > 0 else None  # [1, Mi, D]
+            mesh_lat = Gather2Fn.apply(enc_c, inv, c.maps_mesh, M, B)                   # [B, M, D]
         if self.using_sparse_gat:
             processed, new_edge_index = self.processor.forward(
                 X=mesh_lat, edge_index=self.processing_graph, attention_threshold=attention_threshold, **kwargs)
@@ -646,7 +687,7 @@ class WeatherPrediction(nn.Module):
         else:
             processed = self.processor.forward(X=mesh_lat, edge_index=self.processing_graph,
                                                attention_threshold=attention_threshold)
-        dec_in = Gather2Fn.apply(enc_c, processed, c.maps_dec, G + c.U, B)          # [B, G+U, D]
+        dec_in = Gather2Fn.apply(enc_c, processed, maps_dec, G + c.U, B)            # [B, G+U, D]
         gcn_dec = self.decoder.graph_layer.layer_type == GraphLayerType.ConvGCN
         decoded = self.decoder.forward(X=dec_in, edge_index=c.dec_graph, **({"_out_rows": G} if gcn_dec else {}))
         out, grid_lat = (decoded if gcn_dec else decoded[:, :G, :]), enc_c[:, :G, :]

@@ -123,6 +123,32 @@ def test_general_path_matches_compact_path(levels, B):
         assert d <= 2e-5 * float(gc[n_].double().norm()) + 1e-6 * gn, n_
 
 
+@pytest.mark.parametrize("levels,B", [([1, 2], 1), ([1, 2], 5), ([3, 5], 3), ([3, 5], 64)])
+def test_folded_invariant_rows_equal_separate_pass(levels, B):
+    """Compact pipeline: the batch-invariant mesh rows ride through the encoder's launches as r = ceil(Mi / B)
+    isolated nodes per sample (models.py::_fold_setup, functional.py::MeshLatFn) - outputs are bit-identical to the
+    separate B = 1 pass over those rows (every row sees the same arithmetic), gradients agree to summation order."""
+    from graphcast_lite_amd.train import batch_loss
+
+    cfg, m, o = make_pair("baseline", levels)
+    X, y = data(cfg, m._num_grid_nodes, B)
+    assert m._compact_eligible() and m._fold_invariant_rows
+    out_f = m(X.to(DEV))
+    batch_loss(m, X.to(DEV), y.to(DEV)).backward()
+    gf = {n_: p.grad.clone() for n_, p in m.named_parameters()}
+    f = m._compact.fold[B]
+    assert f.r == -(-m._compact.Mi // B) and f.ne == m._num_grid_nodes + m._compact.Md + f.r
+    m.zero_grad()
+    m._fold_invariant_rows = False
+    out_s = m(X.to(DEV))
+    batch_loss(m, X.to(DEV), y.to(DEV)).backward()
+    assert torch.equal(out_f, out_s)
+    gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in gf.values())))
+    for n_, p in m.named_parameters():
+        d = float((p.grad.double() - gf[n_].double()).norm())
+        assert d <= 1e-5 * float(gf[n_].double().norm()) + 1e-7 * gn, n_
+
+
 def test_graph_mode_layernorm_model():
     """A pipeline whose MLP and processor use layer_norm_mode="graph" (SURVEY.md §8a row 9)."""
     from graphcast_lite_amd.models import WeatherPrediction
