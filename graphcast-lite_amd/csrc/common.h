@@ -66,6 +66,9 @@ int launch_reduce_parts(const float* part, int nparts, int64_t pstride, int pld,
 int launch_reduce_parts2(const float* part, int nparts, int64_t pstride, int pld, int off1, float* out0, float* out1,
                          int C, int accumulate, hipStream_t st);
 
+int launch_reduce_parts3(const float* part, int nparts, int64_t pstride, int pld, float* out0, int acc0, float* out1,
+                         int acc1, float* out2, int acc2, int C, hipStream_t st);
+
 }  // namespace gcl
 
 // Device-side graph arrays (owned by the handle).

@@ -1117,6 +1117,16 @@ int launch_reduce_parts2(const float* part, int nparts, int64_t pstride, int pld
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
+// three vectors of one partial record (each padded to pld entries, back to back), each with its own accumulate flag
+int launch_reduce_parts3(const float* part, int nparts, int64_t pstride, int pld, float* out0, int acc0, float* out1,
+                         int acc1, float* out2, int acc2, int C, hipStream_t st) {
+  RedSeg s0{out0, 0, pld, pld, C, C, acc0};
+  RedSeg s1{out1, pld, pld, pld, C, C, acc1};
+  RedSeg s2{out2, 2 * pld, pld, pld, C, C, acc2};
+  launch_reduce_multi(part, nparts, pstride, s0, s1, s2, st);
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
 }  // namespace gcl
 
 namespace {

@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ X
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma;  partial dgamma/dbeta per block
-template <int LPR, bool V>
+// CS: also the column sums of dX (the bias gradient of the layer below: dX is that layer's dY) as a third vector
+template <int LPR, bool V, bool CS>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dY, int64_t lddy,
                                                      const float* __restrict__ X, int64_t ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ stats,
@@ -83,13 +84,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   if (V) vdy = vx = vdx = 1;
   constexpr int RPW = 64 / LPR;
   constexpr int RPB = RPW * 4;
-  __shared__ float red[RPB][LPR * 4 * 2 + 1];
+  constexpr int NV = CS ? 3 : 2;
+  __shared__ float red[RPB][LPR * 4 * NV + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
   const float invF = 1.f / (float)F;
   float g0 = 0, g1 = 0, g2 = 0, g3 = 0;
   if (c0 < F) load4(gamma + c0, c0, F, false, g0, g1, g2, g3);
   float dg0 = 0, dg1 = 0, dg2 = 0, dg3 = 0, db0 = 0, db1 = 0, db2 = 0, db3 = 0;
+  float cs0 = 0, cs1 = 0, cs2 = 0, cs3 = 0;
   for (int64_t row = (int64_t)blockIdx.x * RPB + wave * RPW + sub; row < rows; row += (int64_t)gridDim.x * RPB) {
     float x0 = 0, x1 = 0, x2 = 0, x3 = 0, y0 = 0, y1 = 0, y2 = 0, y3 = 0;
     if (c0 < F) {
@@ -102,9 +105,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     const float q0 = y0 * g0, q1 = y1 * g1, q2 = y2 * g2, q3 = y3 * g3;
     const float m1 = group_sum<LPR>(q0 + q1 + q2 + q3) * invF;
     const float m2 = group_sum<LPR>(q0 * h0 + q1 * h1 + q2 * h2 + q3 * h3) * invF;
-    if (c0 < F)
-      store4(dX + row * lddx + c0, c0, F, vdx, rstd * (q0 - m1 - h0 * m2), rstd * (q1 - m1 - h1 * m2),
-             rstd * (q2 - m1 - h2 * m2), rstd * (q3 - m1 - h3 * m2));
+    const float o0 = rstd * (q0 - m1 - h0 * m2), o1 = rstd * (q1 - m1 - h1 * m2), o2 = rstd * (q2 - m1 - h2 * m2),
+                o3 = rstd * (q3 - m1 - h3 * m2);
+    if (c0 < F) store4(dX + row * lddx + c0, c0, F, vdx, o0, o1, o2, o3);
+    if (CS) {
+      cs0 += (c0 < F) ? o0 : 0.f; cs1 += (c0 + 1 < F) ? o1 : 0.f; cs2 += (c0 + 2 < F) ? o2 : 0.f; cs3 += (c0 + 3 < F) ? o3 : 0.f;
+    }
     dg0 += y0 * h0; dg1 += y1 * h1; dg2 += y2 * h2; dg3 += y3 * h3;
     db0 += y0; db1 += y1; db2 += y2; db3 += y3;
   }
@@ -113,13 +119,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   float* r = red[g];
   r[c0] = dg0; r[c0 + 1] = dg1; r[c0 + 2] = dg2; r[c0 + 3] = dg3;
   r[LPR * 4 + c0] = db0; r[LPR * 4 + c0 + 1] = db1; r[LPR * 4 + c0 + 2] = db2; r[LPR * 4 + c0 + 3] = db3;
+  if (CS) {
+    r[2 * LPR * 4 + c0] = cs0; r[2 * LPR * 4 + c0 + 1] = cs1; r[2 * LPR * 4 + c0 + 2] = cs2; r[2 * LPR * 4 + c0 + 3] = cs3;
+  }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 2 * LPR * 4; idx += 256) {
+  for (int idx = threadIdx.x; idx < NV * LPR * 4; idx += 256) {
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < RPB; ++q) s += red[q][idx];
     const int which = idx / (LPR * 4), c = idx % (LPR * 4);
-    if (c < F) part[(size_t)blockIdx.x * 2 * FP + which * FP + c] = s;
+    if (c < F) part[(size_t)blockIdx.x * NV * FP + which * FP + c] = s;  // record: dgamma | dbeta (| colsum dX)
   }
 }
 
@@ -198,13 +207,13 @@ extern "C" int gcl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
 extern "C" size_t gcl_layernorm_bwd_ws_bytes(int64_t rows, int32_t F) {
   (void)rows;
   const size_t FP = (size_t)((F + 3) / 4) * 4;
-  return (size_t)kNormBlocks * 2 * FP * sizeof(float);
+  return (size_t)kNormBlocks * 3 * FP * sizeof(float);
 }
 
-extern "C" int gcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
-                                 const float* stats, float* dx, int64_t lddx, float* dgamma, float* dbeta,
-                                 int32_t accumulate, int64_t rows, int32_t F, void* ws, size_t ws_bytes,
-                                 gcl_stream_t stream) {
+extern "C" int gcl_layernorm_bwd_cs(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                                    const float* stats, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                                    float* colsum_dx, int32_t accumulate, int64_t rows, int32_t F, void* ws,
+                                    size_t ws_bytes, gcl_stream_t stream) {
   GCL_CHECK_ARG(dy && x && gamma && stats && dx && dgamma && dbeta, "layernorm_bwd: null argument");
   GCL_CHECK_ARG(F >= 1 && F <= 256 && ldx >= F && lddy >= F && lddx >= F, "layernorm_bwd: bad shape F=%d", F);
   GCL_CHECK_ARG(ws && ws_bytes >= gcl_layernorm_bwd_ws_bytes(rows, F), "layernorm_bwd: workspace too small");
@@ -217,17 +226,33 @@ extern "C" int gcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
   if (nb > kNormBlocks) nb = kNormBlocks;
   float* part = (float*)ws;
   const int vdy = vec_ok(dy, lddy, F), vx = vec_ok(x, ldx, F), vdx = vec_store_ok(dx, lddx, F);
-#define CALL(L)                                                                                                  \
-  if (vdy && vx && vdx)                                                                                          \
-    hipLaunchKernelGGL((ln_bwd_kernel<L, true>), dim3((unsigned)nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma,  \
-                       stats, dx, lddx, part, rows, F, FP, vdy, vx, vdx);                                        \
-  else                                                                                                           \
-    hipLaunchKernelGGL((ln_bwd_kernel<L, false>), dim3((unsigned)nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma, \
-                       stats, dx, lddx, part, rows, F, FP, vdy, vx, vdx)
+  // dgamma / dbeta share GCL_ACC_DW, the column sums have their own bit (they belong to another parameter)
+  const int acc_p = (accumulate & GCL_ACC_DW) ? 1 : 0, acc_cs = (accumulate & GCL_ACC_COLSUM) ? 1 : 0;
+#define CALL3(L, V_, CS_)                                                                                        \
+  hipLaunchKernelGGL((ln_bwd_kernel<L, V_, CS_>), dim3((unsigned)nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma, \
+                     stats, dx, lddx, part, rows, F, FP, vdy, vx, vdx)
+#define CALL(L)                                     \
+  if (vdy && vx && vdx) {                           \
+    if (colsum_dx) CALL3(L, true, true);            \
+    else CALL3(L, true, false);                     \
+  } else {                                          \
+    if (colsum_dx) CALL3(L, false, true);           \
+    else CALL3(L, false, false);                    \
+  }
   GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
+#undef CALL3
   GCL_CHECK_LAUNCH();
-  return gcl::launch_reduce_parts2(part, (int)nb, 2 * FP, FP, FP, dgamma, dbeta, F, accumulate, st);
+  if (!colsum_dx) return gcl::launch_reduce_parts2(part, (int)nb, 2 * FP, FP, FP, dgamma, dbeta, F, acc_p, st);
+  return gcl::launch_reduce_parts3(part, (int)nb, 3 * FP, FP, dgamma, acc_p, dbeta, acc_p, colsum_dx, acc_cs, F, st);
+}
+
+extern "C" int gcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                                 const float* stats, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                                 int32_t accumulate, int64_t rows, int32_t F, void* ws, size_t ws_bytes,
+                                 gcl_stream_t stream) {
+  return gcl_layernorm_bwd_cs(dy, lddy, x, ldx, gamma, stats, dx, lddx, dgamma, dbeta, nullptr,
+                              accumulate ? GCL_ACC_DW : 0, rows, F, ws, ws_bytes, stream);
 }
 
 extern "C" size_t gcl_colsum_ws_bytes(int64_t rows, int32_t F) {

@@ -12,6 +12,8 @@ uses); otherwise it returns a fresh gradient tensor and autograd stores it as us
 """
 from typing import List, Optional
 
+import os
+
 import torch
 
 from . import hip
@@ -120,6 +122,9 @@ class MLPFn(torch.autograd.Function):
 # GCN stack: conv -> PReLU(shared) -> conv -> ... -> conv (-> LayerNorm node)
 # params layout: [W1, b1, ..., WL, bL, slope] (+ [gamma, beta]);  slope may be None when L == 1
 # ------------------------------------------------------------------------------------------------
+_LN_COLSUM = os.environ.get("GCL_NO_LN_COLSUM", "0") in ("0", "")
+
+
 class GCNStackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, owner, graph, L: int, has_ln: bool, eps: float, out_rows: int, *params):
@@ -194,12 +199,18 @@ class GCNStackFn(torch.autograd.Function):
         dy_rows = dy3  # gradient of the rows that were returned (bias gradient of the last conv sums these)
         if ctx.out_rows and (ctx.has_ln or pad is None):
             dy3 = hip.pad_rows(dy3, n, dy3.shape[2])  # rows that were not returned carry a zero gradient
+        bi_last = 2 * L - 1
+        cs_done = False
         if ctx.has_ln:
             gi, bi = len(params) - 2, len(params) - 1
             dgam = G.dst[gi] if G.dst[gi] is not None else torch.zeros_like(params[gi])
             dbet = G.dst[bi] if G.dst[bi] is not None else torch.zeros_like(params[bi])
+            # the LayerNorm backward also sums its dx over the rows: that IS the bias gradient of the last conv
+            cs = G.dst[bi_last] if (pad is None and _LN_COLSUM) else None
             dp = hip.layernorm_bwd(dy3.view(B * n, -1), ps[-1].view(B * n, -1), params[gi].detach(), ctx.stats, dgam,
-                                   dbet, G.acc[gi] and G.acc[bi]).view(B, n, -1)
+                                   dbet, G.acc[gi] and G.acc[bi], colsum_dx=cs,
+                                   acc_colsum=bool(cs is not None and G.acc[bi_last])).view(B, n, -1)
+            cs_done = cs is not None
         else:
             dp = dy3
         si = 2 * L
@@ -214,8 +225,7 @@ class GCNStackFn(torch.autograd.Function):
             # - the padding columns only ever meet zero weights - so dW / dX need no padded weight copy.
             Fp = pad[0]
             dp = hip.pad_rows(dy_rows if not ctx.has_ln else dp, n, Fp)
-        bi_last = 2 * L - 1
-        if G.dst[bi_last] is not None:  # bias of the last conv: its dp comes from outside this stack
+        if G.dst[bi_last] is not None and not cs_done:  # bias of the last conv: its dp comes from outside this stack
             src = dy_rows if not ctx.has_ln else dp[..., :Fo]
             hip.colsum(src.reshape(-1, Fo), G.dst[bi_last], G.acc[bi_last])
         for k in range(L - 1, -1, -1):

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "gcl_gat_prune_ws_bytes": (_sz, [_i64]),
     "gcl_layernorm_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _vp, _i64, _vp, _i64, _i32, _vp]),
     "gcl_layernorm_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i64, _i32, _vp, _sz, _vp]),
+    "gcl_layernorm_bwd_cs": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _sz, _vp]),
     "gcl_layernorm_bwd_ws_bytes": (_sz, [_i64, _i32]),
     "gcl_graphnorm_fwd": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _f32, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "gcl_graphnorm_bwd": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f32, _vp, _i64, _i64, _vp, _vp,
@@ -378,13 +379,16 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y, stats
 
 
-def layernorm_bwd(dy, x, gamma, stats, dgamma, dbeta, accumulate: bool):
+def layernorm_bwd(dy, x, gamma, stats, dgamma, dbeta, accumulate: bool, colsum_dx=None, acc_colsum: bool = False):
+    """dx of the node LayerNorm (+ dgamma, dbeta); `colsum_dx` also receives the column sums of dx (the bias
+    gradient of the layer below) from the same pass."""
     rows, F = x.shape
     dx = torch.empty(rows, F, dtype=torch.float32, device=x.device)
     nb = lib().gcl_layernorm_bwd_ws_bytes(rows, F)
     ws = workspace(nb, x.device)
-    _check(lib().gcl_layernorm_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), _p(stats), _p(dx), F, _p(dgamma),
-                                   _p(dbeta), 1 if accumulate else 0, rows, F, ws.data_ptr(), ws.numel(), _stream()))
+    acc = (ACC_DW if accumulate else 0) | (ACC_COLSUM if acc_colsum else 0)
+    _check(lib().gcl_layernorm_bwd_cs(_p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), _p(stats), _p(dx), F, _p(dgamma),
+                                      _p(dbeta), _p(colsum_dx), acc, rows, F, ws.data_ptr(), ws.numel(), _stream()))
     return dx
 
 

@@ -205,6 +205,14 @@ int gcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx
                       const float* stats, float* dx, int64_t lddx, float* dgamma, float* dbeta,
                       int32_t accumulate, int64_t rows, int32_t F, void* ws, size_t ws_bytes,
                       gcl_stream_t stream);
+/* Same, and colsum_dx[j] (+)= sum over rows of dx[:, j] when colsum_dx != NULL: dx is the dY of the layer below,
+ * so this is that layer's bias gradient (GCNConv.bias of the last conv under the stack's LayerNorm,
+ * src/models.py:368-374,419) without a second pass over dx.  accumulate: GCL_ACC_DW covers dgamma and dbeta,
+ * GCL_ACC_COLSUM the column sums. */
+int gcl_layernorm_bwd_cs(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                         const float* stats, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                         float* colsum_dx, int32_t accumulate, int64_t rows, int32_t F, void* ws,
+                         size_t ws_bytes, gcl_stream_t stream);
 size_t gcl_layernorm_bwd_ws_bytes(int64_t rows, int32_t F);
 /* PyG LayerNorm(mode="graph"): statistics over all n*F elements of each sample, eps added to the
  * std.  stats [B,2] = (mean, 1/(std+eps)). */

@@ -321,6 +321,15 @@ def test_layernorm(hip, rows, F):
     dg, db = torch.empty(F, device=DEV), torch.empty(F, device=DEV)
     dx = hip.layernorm_bwd(dy.to(DEV), x.detach().to(DEV), gm.detach().to(DEV), stats, dg, db, False)
     assert rel(dx, x.grad) < 2e-5 and rel(dg, gm.grad) < 2e-5 and rel(db, bt.grad) < TOL
+    # the same pass can also sum dx over the rows (bias gradient of the layer below), with its own accumulate bit
+    dg2, db2, cs = torch.ones(F, device=DEV), torch.ones(F, device=DEV), torch.full((F,), 2.0, device=DEV)
+    dx2 = hip.layernorm_bwd(dy.to(DEV), x.detach().to(DEV), gm.detach().to(DEV), stats, dg2, db2, False, colsum_dx=cs,
+                            acc_colsum=True)
+    assert rel(dx2, dx) < 1e-6 and rel(dg2, dg) < 1e-6 and rel(db2, db) < 1e-6
+    ref_cs = x.grad.double().sum(0)
+    assert float((cs.cpu().double() - 2.0 - ref_cs).abs().max()) <= 1e-5 * float(x.grad.abs().sum(0).max()) + 1e-6
+    hip.layernorm_bwd(dy.to(DEV), x.detach().to(DEV), gm.detach().to(DEV), stats, dg2, db2, True, colsum_dx=cs, acc_colsum=False)
+    assert rel(dg2, 2 * gm.grad) < 2e-5 and float((cs.cpu().double() - ref_cs).abs().max()) <= 1e-5 * float(x.grad.abs().sum(0).max()) + 1e-6
 
 
 @pytest.mark.parametrize("B,n,F", [(3, 500, 64), (1, 162, 33), (2, 3000, 128), (2, 7, 12)])
