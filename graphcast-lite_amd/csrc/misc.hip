@@ -3,6 +3,31 @@
 
 namespace {
 
+// (b, i, c) of a flat index over [B][N][C] that a thread walks with a fixed stride, kept incrementally.  The GPU has
+// no integer divide: the naive `idx % C, (idx / C) % N, idx / (C * N)` costs two 64-bit divisions (~40 instructions
+// each) per ELEMENT and made these streaming kernels instruction-bound (2.2-2.7 TB/s); here they are paid once per thread.
+struct Walk3 {
+  int c, i, C, N, sc, si;
+  int64_t b, sb;
+  __device__ __forceinline__ Walk3(int64_t idx, int64_t stride, int N_, int C_) : C(C_), N(N_) {
+    c = (int)(idx % C_);
+    const int64_t r = idx / C_;
+    i = (int)(r % N_);
+    b = r / N_;
+    sc = (int)(stride % C_);
+    const int64_t t = stride / C_;
+    si = (int)(t % N_);
+    sb = t / N_;
+  }
+  __device__ __forceinline__ void next() {
+    c += sc;
+    i += si;
+    b += sb;
+    if (c >= C) { c -= C; ++i; }
+    if (i >= N) { i -= N; ++b; }
+  }
+};
+
 // out[b, i, :] = i < G ? [x[b,i,:Cdyn] | gstat[i,:Cs]] : [0 | mstat[i-G,:Cs]]
 // (src/models.py:776-806; the reference allocates the zero block and concatenates 3x per forward)
 __global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__ x, const float* __restrict__ gs,
@@ -11,17 +36,17 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__
                                                        int32_t Cs) {
   const int C = Cdyn + Cs;
   const int64_t total = (int64_t)B * (G + M) * C;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int c = (int)(idx % C);
-    const int64_t bi = idx / C;
-    const int i = (int)(bi % (G + M));
-    const int64_t b = bi / (G + M);
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (Walk3 w(idx, stride, G + M, C); idx < total; idx += stride, w.next()) {
+    const int c = w.c, i = w.i;
+    const int64_t b = w.b;
     float v;
     if (i < G)
       v = c < Cdyn ? x[(b * G + i) * Cdyn + c] : gs[(int64_t)i * Cs + (c - Cdyn)];
     else
       v = c < Cdyn ? 0.f : ms[(int64_t)(i - G) * Cs + (c - Cdyn)];
-    out[bi * ldo + c] = v;
+    out[(b * (G + M) + i) * ldo + c] = v;
   }
 }
 
@@ -36,11 +61,11 @@ __global__ __launch_bounds__(256) void wmse_kernel(const float* __restrict__ del
   __shared__ float red[4];
   const int64_t total = (int64_t)B * G * C;
   float acc = 0.f;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int c = (int)(idx % C);
-    const int64_t bg = idx / C;
-    const int g = (int)(bg % G);
-    const int64_t b = bg / G;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (Walk3 wk(idx, stride, G, C); idx < total; idx += stride, wk.next()) {
+    const int c = wk.c, g = wk.i;
+    const int64_t b = wk.b;
     float o = delta[b * bsd + (int64_t)g * ldd + c];
     if (xl) o += xl[b * bsx + (int64_t)g * ldx + c];
     const float t = y[b * bsy + (int64_t)g * ldy + c];
@@ -152,11 +177,11 @@ __global__ __launch_bounds__(256) void gather2_kernel(const float* __restrict__ 
                                                       int64_t ldd, int64_t bsd, int32_t B, int32_t nd, int32_t F4,
                                                       int32_t sum_batch) {
   const int64_t total = (int64_t)(sum_batch ? 1 : B) * nd * F4;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int c = (int)(idx % F4) * 4;
-    const int64_t bi = idx / F4;
-    const int i = (int)(bi % nd);
-    const int64_t b = bi / nd;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (Walk3 w(idx, stride, nd, F4); idx < total; idx += stride, w.next()) {
+    const int c = w.c * 4, i = w.i;
+    const int64_t b = w.b;
     const int ja = map_a ? map_a[i] : i;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (sum_batch) {
@@ -258,10 +283,11 @@ __global__ __launch_bounds__(256) void ar_step_bwd_kernel(const float* __restric
                                                           int32_t C) {
   const float gl = g_loss ? *g_loss : 1.f;
   const int64_t total = (int64_t)B * G * obs * C;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int c = (int)(idx % C);
-    const int k = (int)((idx / C) % obs);
-    const int64_t bg = idx / ((int64_t)C * obs);
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (Walk3 w(idx, stride, obs, C); idx < total; idx += stride, w.next()) {
+    const int c = w.c, k = w.i;
+    const int64_t bg = w.b;
     float ds = (g_new && k >= 1) ? g_new[idx - C] : 0.f;
     if (k == obs - 1) {
       int kind = chan_kind ? chan_kind[c] : 0;
@@ -283,11 +309,11 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__
                                                        int64_t ldd, int64_t bsd, int32_t rows_dst, int32_t F_dst,
                                                        int32_t B) {
   const int64_t total = (int64_t)B * rows_dst * F_dst;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int c = (int)(idx % F_dst);
-    const int64_t br = idx / F_dst;
-    const int r = (int)(br % rows_dst);
-    const int64_t b = br / rows_dst;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (Walk3 w(idx, stride, rows_dst, F_dst); idx < total; idx += stride, w.next()) {
+    const int c = w.c, r = w.i;
+    const int64_t b = w.b;
     const bool in = r < rows_src && c < F_src;
     dst[b * bsd + (int64_t)r * ldd + c] = in ? src[b * bss + (int64_t)r * lds + c] : 0.f;
   }
