@@ -1007,6 +1007,9 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const float* __restri
 // Same contract, 16-byte loads: a block reduces 32 consecutive floats of the record (8 lanes x float4 =
 // one 128-B line per partial record) with 32 groups of lanes striding over the records, then a
 // fixed-order combine through LDS.  Needs pstride, every poff and every count to be multiples of 4.
+__device__ __forceinline__ void reduce4_block(const float* __restrict__ part, int32_t nparts, int64_t pstride,
+                                              const RedSeg& s0, const RedSeg& s1, const RedSeg& s2, int blk);
+
 __global__ __launch_bounds__(256) void reduce_multi4_kernel(const float* __restrict__ part, int32_t nparts,
                                                             int64_t pstride, RedSeg s0, RedSeg s1, RedSeg s2,
                                                             const double* __restrict__ spart, int32_t ns,
@@ -1020,9 +1023,14 @@ __global__ __launch_bounds__(256) void reduce_multi4_kernel(const float* __restr
     }
     return;
   }
+  reduce4_block(part, nparts, pstride, s0, s1, s2, blockIdx.x);
+}
+
+__device__ __forceinline__ void reduce4_block(const float* __restrict__ part, int32_t nparts, int64_t pstride,
+                                              const RedSeg& s0, const RedSeg& s1, const RedSeg& s2, int blk) {
   __shared__ float red[32][33];
   const int l8 = threadIdx.x & 7, g = threadIdx.x >> 3;
-  int idx = blockIdx.x * 32 + l8 * 4;  // first of this lane's 4 elements, in the concatenated segments
+  int idx = blk * 32 + l8 * 4;  // first of this lane's 4 elements, in the concatenated segments
   RedSeg sg = s0;
   if (idx >= s0.count) {
     idx -= s0.count;
@@ -1056,7 +1064,7 @@ __global__ __launch_bounds__(256) void reduce_multi4_kernel(const float* __restr
   __syncthreads();
   if (threadIdx.x < 32) {
     // element threadIdx.x of the block: recompute its segment position (its lane group's idx + offset)
-    int e = blockIdx.x * 32 + threadIdx.x;
+    int e = blk * 32 + threadIdx.x;
     RedSeg so = s0;
     if (e >= s0.count) {
       e -= s0.count;
@@ -1094,6 +1102,42 @@ inline void launch_reduce_multi(const float* part, int nparts, int64_t pstride, 
   else
     hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)gcl::cdiv(total, 16) + extra), dim3(256), 0, st, part, nparts,
                        pstride, s0, s1, s2, sp, ns, sout);
+}
+
+// Final pass of up to 16 fused backward calls in ONE launch (gcl_reduce_jobs): block -> (job, block of the job).
+// The scalar (PReLU slope) partials of ALL jobs are summed by the last block, job after job, so jobs that share a
+// slope parameter add to it in a fixed order.
+constexpr int kJobsPerLaunch = 16;
+struct RedJobK {
+  const float* part;
+  int64_t pstride;
+  RedSeg s0, s1, s2;
+  const double* spart;
+  float* sout;
+  int32_t nparts, ns, blk0;  // blk0: first block of this job in the launch
+};
+struct RedJobsK {
+  RedJobK j[kJobsPerLaunch];
+  int32_t n, nblk;
+};
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(RedJobsK J) {
+  const int blk = blockIdx.x;
+  if (blk == J.nblk) {  // the extra block: scalar partials, in job order
+    if (threadIdx.x < 64) {
+      for (int q = 0; q < J.n; ++q) {
+        if (!J.j[q].spart) continue;
+        double t = 0.0;
+        for (int p = threadIdx.x; p < J.j[q].ns; p += 64) t += J.j[q].spart[p];
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if (threadIdx.x == 0) *J.j[q].sout += (float)t;
+      }
+    }
+    return;
+  }
+  int q = 0;
+  while (q + 1 < J.n && blk >= J.j[q + 1].blk0) ++q;  // uniform
+  const RedJobK& jb = J.j[q];
+  reduce4_block(jb.part, jb.nparts, jb.pstride, jb.s0, jb.s1, jb.s2, blk - jb.blk0);
 }
 
 }  // namespace
@@ -1511,10 +1555,11 @@ extern "C" size_t gcl_linear_bwd_all_ws_bytes(int64_t rows, int32_t Fin, int32_t
   return fused > sep ? fused : sep;
 }
 
-extern "C" int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W, const float* x, int64_t ldx,
-                                  const float* in_slope, float* d_in_slope, float* dx, int64_t lddx, float* dW,
-                                  float* db, float* colsum_dx, int64_t rows, int32_t Fin, int32_t Fout,
-                                  int32_t accumulate, void* ws, size_t ws_bytes, gcl_stream_t stream) {
+static int bwd_all_impl(const float* dy, int64_t lddy, const float* W, const float* x, int64_t ldx,
+                        const float* in_slope, float* d_in_slope, float* dx, int64_t lddx, float* dW,
+                        float* db, float* colsum_dx, int64_t rows, int32_t Fin, int32_t Fout,
+                        int32_t accumulate, void* ws, size_t ws_bytes, gcl_stream_t stream, gcl_reduce_job* job) {
+  if (job) memset(job, 0, sizeof(*job));
   GCL_CHECK_ARG(dy && W && x && dx && dW, "linear_bwd_all: null argument");
   GCL_CHECK_ARG(ws && ws_bytes >= gcl_linear_bwd_all_ws_bytes(rows, Fin, Fout), "linear_bwd_all: workspace too small");
   hipStream_t st = (hipStream_t)stream;
@@ -1536,7 +1581,7 @@ extern "C" int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W,
                            ws, ws_bytes, stream);
     if (rc) return rc;
     if (colsum_dx) rc = gcl_colsum(dx, lddx, rows, Fin, colsum_dx, acc_cs, ws, ws_bytes, stream);
-    return rc;
+    return rc;  // (nothing deferred: job stays empty)
   }
   const int NO = (Fout + 31) / 32, NC = (Fin + 31) / 32;
   const int FoP = NO * 32, FiP = NC * 32;
@@ -1595,8 +1640,91 @@ extern "C" int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W,
     RedSeg s0{dW, 0, Fout * FiP, FiP, Fin, Fin, acc_dw};
     RedSeg s1{db, FoP * FiP, db ? Fout : 0, FoP, Fout, 0, acc_db};
     RedSeg s2{colsum_dx, FoP * FiP + FoP, colsum_dx ? Fin : 0, FiP, Fin, 0, acc_cs};
+    if (job) {
+      // deferred: describe the final pass instead of launching it.  db / colsum segments are widened to their padded
+      // lengths (cols still limits what is written) so that every job takes the 16-byte reducer.
+      s1.count = db ? FoP : 0;
+      s2.count = colsum_dx ? FiP : 0;
+      job->part = part_dw;
+      job->nparts = nblk;
+      job->pstride = rec;
+      const RedSeg* ss[3] = {&s0, &s1, &s2};
+      for (int q = 0; q < 3; ++q) {
+        job->seg[q].out = ss[q]->out;
+        job->seg[q].poff = ss[q]->poff;
+        job->seg[q].count = ss[q]->count;
+        job->seg[q].pld = ss[q]->pld;
+        job->seg[q].cols = ss[q]->cols;
+        job->seg[q].ldo = ss[q]->ldo;
+        job->seg[q].acc = ss[q]->acc;
+      }
+      job->spart = want_slope ? part_sl : nullptr;
+      job->ns = want_slope ? nblk : 0;
+      job->sout = want_slope ? d_in_slope : nullptr;
+      return GCL_OK;
+    }
     // + the slope partials (one extra block of the same launch)
     launch_reduce_multi(part_dw, nblk, rec, s0, s1, s2, st, want_slope ? part_sl : nullptr, nblk, d_in_slope);
+    GCL_CHECK_LAUNCH();
+  }
+  return GCL_OK;
+}
+
+extern "C" int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W, const float* x, int64_t ldx,
+                                  const float* in_slope, float* d_in_slope, float* dx, int64_t lddx, float* dW,
+                                  float* db, float* colsum_dx, int64_t rows, int32_t Fin, int32_t Fout,
+                                  int32_t accumulate, void* ws, size_t ws_bytes, gcl_stream_t stream) {
+  return bwd_all_impl(dy, lddy, W, x, ldx, in_slope, d_in_slope, dx, lddx, dW, db, colsum_dx, rows, Fin, Fout,
+                      accumulate, ws, ws_bytes, stream, nullptr);
+}
+
+extern "C" int gcl_linear_bwd_all_deferred(const float* dy, int64_t lddy, const float* W, const float* x, int64_t ldx,
+                                           const float* in_slope, float* d_in_slope, float* dx, int64_t lddx,
+                                           float* dW, float* db, float* colsum_dx, int64_t rows, int32_t Fin,
+                                           int32_t Fout, int32_t accumulate, void* ws, size_t ws_bytes,
+                                           gcl_stream_t stream, gcl_reduce_job* job) {
+  GCL_CHECK_ARG(job, "linear_bwd_all_deferred: null job");
+  return bwd_all_impl(dy, lddy, W, x, ldx, in_slope, d_in_slope, dx, lddx, dW, db, colsum_dx, rows, Fin, Fout,
+                      accumulate, ws, ws_bytes, stream, job);
+}
+
+extern "C" int gcl_reduce_jobs(const gcl_reduce_job* jobs, int32_t n, gcl_stream_t stream) {
+  GCL_CHECK_ARG(n >= 0 && (jobs || n == 0), "reduce_jobs: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  for (int32_t base = 0; base < n; base += kJobsPerLaunch) {
+    RedJobsK J;
+    memset(&J, 0, sizeof(J));
+    int nb = 0, cnt = 0;
+    bool any_slope = false;
+    for (int32_t q = base; q < n && cnt < kJobsPerLaunch; ++q) {
+      const gcl_reduce_job& g = jobs[q];
+      if (g.nparts <= 0) continue;  // that call reduced on the spot
+      GCL_CHECK_ARG(g.part && g.pstride % 4 == 0 && gcl::aligned16(g.part), "reduce_jobs: bad partial buffer");
+      RedJobK& k = J.j[cnt];
+      k.part = g.part;
+      k.pstride = g.pstride;
+      RedSeg* ss[3] = {&k.s0, &k.s1, &k.s2};
+      int total = 0;
+      for (int t = 0; t < 3; ++t) {
+        GCL_CHECK_ARG((g.seg[t].poff | g.seg[t].count) % 4 == 0, "reduce_jobs: segment not 16-byte granular");
+        *ss[t] = RedSeg{g.seg[t].out, g.seg[t].poff, g.seg[t].out ? g.seg[t].count : 0, g.seg[t].pld > 0 ? g.seg[t].pld : 1,
+                        g.seg[t].cols, g.seg[t].ldo, g.seg[t].acc};
+        total += ss[t]->count;
+      }
+      k.spart = g.spart;
+      k.sout = g.sout;
+      k.nparts = g.nparts;
+      k.ns = g.ns;
+      k.blk0 = nb;
+      any_slope = any_slope || (g.spart && g.sout && g.ns > 0);
+      if (!(g.spart && g.sout && g.ns > 0)) k.spart = nullptr;
+      nb += (int)gcl::cdiv(total, 32);
+      ++cnt;
+    }
+    if (cnt == 0) continue;
+    J.n = cnt;
+    J.nblk = nb;
+    hipLaunchKernelGGL(reduce_jobs_kernel, dim3((unsigned)nb + (any_slope ? 1u : 0u)), dim3(256), 0, st, J);
     GCL_CHECK_LAUNCH();
   }
   return GCL_OK;

@@ -38,6 +38,9 @@ _SIGNATURES = {
     "gcl_linear_bwd_ws_bytes": (_sz, [_i64, _i32, _i32]),
     "gcl_linear_bwd_all": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32,
                                      _i32, _vp, _sz, _vp]),
+    "gcl_linear_bwd_all_deferred": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32,
+                                              _i32, _i32, _vp, _sz, _vp, _vp]),
+    "gcl_reduce_jobs": (C.c_int, [_vp, _i32, _vp]),
     "gcl_linear_bwd_all_ws_bytes": (_sz, [_i64, _i32, _i32]),
     "gcl_aggregate": (C.c_int, [_vp, _i32, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "gcl_gat_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
@@ -326,6 +329,58 @@ def dense_bwd_dw(dy, x, dW, db, accumulate: bool, act=ACT_NONE, slope=None):
 ACC_DW, ACC_DB, ACC_COLSUM = 1, 2, 4  # GCL_ACC_* bits of gcl_linear_bwd_all
 
 
+class _RedSeg(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("poff", C.c_int32), ("count", C.c_int32), ("pld", C.c_int32), ("cols", C.c_int32),
+                ("ldo", C.c_int32), ("acc", C.c_int32)]
+
+
+class ReduceJob(C.Structure):
+    """Mirror of gcl_reduce_job (include/gcl.h)."""
+    _fields_ = [("part", C.c_void_p), ("pstride", C.c_int64), ("seg", _RedSeg * 3), ("spart", C.c_void_p),
+                ("sout", C.c_void_p), ("nparts", C.c_int32), ("ns", C.c_int32)]
+
+
+class _Deferred:
+    """Pending final passes of the fused dense backward (gcl_linear_bwd_all_deferred): a training step opens the
+    queue before its backward and flushes it once afterwards - one launch per 16 layers instead of one per layer.
+    Every pending call owns a workspace from a pool that persists across steps (a replayed hipGraph keeps using it)."""
+
+    def __init__(self):
+        self.active = False
+        self.jobs, self.dests, self.pool, self.used = [], set(), [], 0
+
+    def ws(self, nbytes, device):
+        if self.used == len(self.pool):
+            self.pool.append(None)
+        cur = self.pool[self.used]
+        if cur is None or cur.numel() < nbytes or cur.device != torch.device(device):
+            if cur is not None:
+                _ws_retired.append(cur)
+            cur = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self.pool[self.used] = cur
+        self.used += 1
+        return cur
+
+
+_deferred = _Deferred()
+
+
+def defer_begin():
+    """Open the deferred-reduction queue (idempotent); pair with defer_flush()."""
+    _deferred.active = True
+
+
+def defer_flush(close: bool = True):
+    """Run the pending final passes (gcl_reduce_jobs) on the current stream."""
+    d = _deferred
+    if d.jobs:
+        arr = (ReduceJob * len(d.jobs))(*d.jobs)
+        _check(lib().gcl_reduce_jobs(C.cast(arr, C.c_void_p), len(d.jobs), _stream()))
+    d.jobs, d.dests, d.used = [], set(), 0
+    if close:
+        d.active = False
+
+
 def linear_bwd_all(dy, W, x, in_slope, d_in_slope, dW, db, colsum_dx, acc_dW: bool, acc_db=None, acc_colsum=None,
                    act=None):
     """dx (pre-activation gradient) + dW (+ db, slope gradient, column sums of dx) in one call.
@@ -348,12 +403,29 @@ def linear_bwd_all(dy, W, x, in_slope, d_in_slope, dW, db, colsum_dx, acc_dW: bo
     Fin = W.shape[1]
     dx = torch.empty(rows, Fin, dtype=torch.float32, device=dy.device)
     nb = lib().gcl_linear_bwd_all_ws_bytes(rows, Fin, Fout)
+    acc = (ACC_DW if acc_dW else 0) | (ACC_DB if acc_db else 0) | (ACC_COLSUM if acc_colsum else 0)
+    d = _deferred
+    if d.active:
+        # two pending passes must not write the same destination (a layer that runs twice in one backward, e.g. an
+        # autoregressive rollout): flush what is queued first
+        dests = {t.data_ptr() for t in (dW, db, colsum_dx) if t is not None}
+        if dests & d.dests:
+            defer_flush(close=False)
+        ws = d.ws(nb, dy.device)
+        job = ReduceJob()
+        _check(lib().gcl_linear_bwd_all_deferred(
+            _p(dy), _ld(dy), _p(W), _p(x), _ld(x), _p(in_slope), _p(d_in_slope), _p(dx), Fin, _p(dW), _p(db),
+            _p(colsum_dx), rows, Fin, Fout, acc, ws.data_ptr(), ws.numel(), _stream(), C.byref(job)))
+        if job.nparts > 0:
+            d.jobs.append(job)
+            d.dests |= dests
+        else:
+            d.used -= 1  # reduced on the spot: the workspace slot is free again
+        return dx
     ws = workspace(nb, dy.device)
     _check(lib().gcl_linear_bwd_all(
         _p(dy), _ld(dy), _p(W), _p(x), _ld(x), _p(in_slope), _p(d_in_slope), _p(dx), Fin, _p(dW), _p(db),
-        _p(colsum_dx), rows, Fin, Fout,
-        (ACC_DW if acc_dW else 0) | (ACC_DB if acc_db else 0) | (ACC_COLSUM if acc_colsum else 0),
-        ws.data_ptr(), ws.numel(), _stream()))
+        _p(colsum_dx), rows, Fin, Fout, acc, ws.data_ptr(), ws.numel(), _stream()))
     return dx
 
 

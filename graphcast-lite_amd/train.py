@@ -357,6 +357,9 @@ class FusedAdam:
         self.step_dev.fill_(steps.pop() if steps else 0)
 
 
+_DEFER_REDUCTIONS = os.environ.get("GCL_NO_DEFER", "0") in ("0", "")
+
+
 class TrainStep:
     """One optimiser step on a local batch: forward, loss, backward, [all-reduce], Adam.
 
@@ -417,7 +420,16 @@ class TrainStep:
         loss = batch_loss(self.model, X, y, threshold, epoch, batch_num, self.lat_weights, self.ar_steps,
                           self.channel_mask, self.spatial_mask, self.static_channels, self.forcing_channels,
                           self.use_residual)
-        loss.backward()
+        # every parameter gradient lands in the flat bucket (preinstalled .grad slices) and is only read after the whole
+        # backward, so the small final passes of the fused dense backward are queued and run in one launch per 16 layers
+        defer = _DEFER_REDUCTIONS and loss.is_cuda
+        if defer:
+            hip.defer_begin()
+        try:
+            loss.backward()
+        finally:
+            if defer:
+                hip.defer_flush()
         return loss.detach()
 
     def _finish(self):

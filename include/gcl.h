@@ -122,6 +122,31 @@ int gcl_linear_bwd_all(const float* dy, int64_t lddy, const float* W, const floa
                        int32_t accumulate, void* ws, size_t ws_bytes, gcl_stream_t stream);
 size_t gcl_linear_bwd_all_ws_bytes(int64_t rows, int32_t Fin, int32_t Fout);
 
+/* Deferred final pass.  A training step calls gcl_linear_bwd_all once per layer, and each call ends in a small launch
+ * that sums its per-block partial records into dW / db / colsum_dx / the slope gradient.  The _deferred form runs the
+ * main kernel only and DESCRIBES that pass in *job; gcl_reduce_jobs later runs the passes of many calls in one launch
+ * per 16 jobs (the gradients of one optimiser step, src/train.py:232-233, are only read after the whole backward).
+ * Rules: every deferred call needs its OWN workspace, alive until gcl_reduce_jobs has run; two pending jobs must not
+ * write the same dW / db / colsum_dx (flush first; a shared slope gradient is fine: slopes are summed job after job);
+ * job->nparts == 0 means the call took the non-fused path and has already reduced on the spot. */
+typedef struct gcl_reduce_job {
+  const float* part; /* per-block partial records */
+  int64_t pstride;   /* floats between records */
+  struct {
+    float* out; /* NULL: unused segment */
+    int32_t poff, count, pld, cols, ldo, acc;
+  } seg[3];           /* dW | db | colsum_dx */
+  const double* spart; /* slope partials (one per block) or NULL */
+  float* sout;
+  int32_t nparts, ns;
+} gcl_reduce_job;
+int gcl_linear_bwd_all_deferred(const float* dy, int64_t lddy, const float* W, const float* x, int64_t ldx,
+                                const float* in_slope, float* d_in_slope, float* dx, int64_t lddx, float* dW,
+                                float* db, float* colsum_dx, int64_t rows, int32_t Fin, int32_t Fout,
+                                int32_t accumulate, void* ws, size_t ws_bytes, gcl_stream_t stream,
+                                gcl_reduce_job* job);
+int gcl_reduce_jobs(const gcl_reduce_job* jobs, int32_t n, gcl_stream_t stream);
+
 /* General form of the three calls above, for wide layers and fused operands (the InteractionNet
  * processor, src/models.py:185-233, and the 256-wide MLPs): any Fin / Fout, the weight may be a
  * column block of a wider matrix (row stride ldw >= Fin, e.g. one third of edge_mlp[0].weight

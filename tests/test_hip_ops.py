@@ -204,6 +204,45 @@ def test_linear_bwd_all_accumulate_bits(hip, rows, Fin, Fout):
         assert rel(cs - (7.0 if acc[2] else 0.0), xr.grad.sum(0)) < 1e-4, bits
 
 
+def test_deferred_reductions_equal_immediate(hip):
+    """gcl_linear_bwd_all_deferred + gcl_reduce_jobs: the final passes of several layers (different shapes, a shared
+    slope gradient, one layer that runs twice = duplicate destinations, a shape that falls back to the separate
+    kernels) run in one launch and give the same dW / db / colsum / slope as the immediate form."""
+    shapes = [(3000, 64, 64), (777, 48, 33), (5000, 64, 48), (300, 128, 128), (3000, 64, 64)]
+    a = torch.tensor([0.25], device=DEV)
+
+    def run(deferred):
+        outs, da = [], torch.zeros(1, device=DEV)
+        if deferred:
+            hip.defer_begin()
+        keep = {}
+        for k, (rows, Fin, Fout) in enumerate(shapes):
+            x, W, dy = rnd(rows, Fin, seed=10 + k).to(DEV), rnd(Fout, Fin, seed=20 + k, scale=0.2).to(DEV), rnd(rows, Fout, seed=30 + k).to(DEV)
+            ldy = (Fout + 3) // 4 * 4
+            dyp = torch.zeros(rows, ldy, device=DEV)
+            dyp[:, :Fout] = dy
+            if k == 4:  # the same layer again: accumulates on top of call 0's destinations
+                dW, db, cs = keep[0]
+                acc = True
+            else:
+                dW, db, cs = torch.full((Fout, Fin), 2.0, device=DEV), torch.full((Fout,), 3.0, device=DEV), torch.full((Fin,), 4.0, device=DEV)
+                keep[k] = (dW, db, cs)
+                acc = k % 2 == 1
+            dx = hip.linear_bwd_all(dyp[:, :Fout], W, x, a, da, dW, db, cs, acc, acc_db=not acc, acc_colsum=acc)
+            outs.append(dx)
+        if deferred:
+            hip.defer_flush()
+        for k in sorted(keep):
+            outs.extend(keep[k])
+        outs.append(da)
+        return outs
+
+    imm, dfr = run(False), run(True)
+    assert not hip._deferred.active and not hip._deferred.jobs
+    for u, v in zip(imm, dfr):
+        assert rel(v, u) < 2e-6
+
+
 def test_linear_mfma_equals_valu(hip, monkeypatch):
     """The fp32 MFMA path and the plain VALU path of the same entry point agree (both fp32 FMA chains)."""
     import os
