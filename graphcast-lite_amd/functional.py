@@ -453,7 +453,7 @@ class Gather2Fn(torch.autograd.Function):
     batch and receives the batch-summed gradient."""
 
     @staticmethod
-    def forward(ctx, a, b, maps, nd: int, B: int):
+    def forward(ctx, a, b, maps, nd: int, B: int, landing=None):
         map_a, map_b, inv_a, inv_b = maps
         a3 = a.detach()
         b3 = b.detach() if b is not None else None
@@ -461,7 +461,7 @@ class Gather2Fn(torch.autograd.Function):
             a3 = a3.contiguous()
         if b3 is not None and not b3.is_contiguous():
             b3 = b3.contiguous()
-        ctx.maps, ctx.B = maps, B
+        ctx.maps, ctx.B, ctx.landing = maps, B, landing
         ctx.sa, ctx.sb = a3.shape, (b3.shape if b3 is not None else None)
         return hip.gather2_rows(a3, map_a, b3, map_b, nd, B)
 
@@ -472,11 +472,30 @@ class Gather2Fn(torch.autograd.Function):
         da = db = None
         if ctx.needs_input_grad[0]:
             bc = ctx.sa[0] == 1 and ctx.B > 1
-            da = hip.gather2_rows(g, inv_a, None, None, ctx.sa[1], ctx.B, sum_batch=bc)
+            land = ctx.landing
+            if land is not None and land.mesh_pending and not bc:
+                # GradLanding: this call fills the head rows of the shared gradient buffer and hands the WHOLE buffer to
+                # autograd; MeshLatFn.backward (always later: it needs the processor's backward, which needs db below)
+                # fills the tail rows in place and returns None - no zero-filled halves, no add of two full tensors
+                land.buf = torch.empty(ctx.sa, dtype=torch.float32, device=g.device)
+                hip.gather2_rows(g, inv_a, None, None, land.head, ctx.B, out=land.buf[:, : land.head])
+                da = land.buf
+            else:
+                da = hip.gather2_rows(g, inv_a, None, None, ctx.sa[1], ctx.B, sum_batch=bc)
         if ctx.sb is not None and ctx.needs_input_grad[1]:
             bc = ctx.sb[0] == 1 and ctx.B > 1
             db = hip.gather2_rows(g, inv_b, None, None, ctx.sb[1], ctx.B, sum_batch=bc)
-        return da, db, None, None, None
+        return da, db, None, None, None, None
+
+
+class GradLanding:
+    """One gradient buffer shared by the two consumers of the compact encoder output [B, ne, D]: the decoder-input
+    gather only ever sends gradient to the first `head` (grid) rows, the mesh-latent gather only to the rest.  See
+    Gather2Fn.backward / MeshLatFn.backward; used only when nothing else consumes the encoder output with a gradient
+    (WeatherPrediction.forward, not forward_with_latents)."""
+
+    def __init__(self, head: int):
+        self.head, self.buf, self.mesh_pending = head, None, False
 
 
 class MeshLatFn(torch.autograd.Function):
@@ -489,13 +508,15 @@ class MeshLatFn(torch.autograd.Function):
     of g[:, inv_fold[j]]."""
 
     @staticmethod
-    def forward(ctx, enc, maps, M: int, gmd: int, r: int):
+    def forward(ctx, enc, maps, M: int, gmd: int, r: int, landing=None):
         map_a, map_b, inv_a, inv_fold = maps
         e3 = enc.detach()
         if not e3.is_contiguous():
             e3 = e3.contiguous()
         B, ne, D = e3.shape
-        ctx.maps, ctx.shape, ctx.gmd, ctx.r = maps, (B, ne, D), gmd, r
+        ctx.maps, ctx.shape, ctx.gmd, ctx.r, ctx.landing = maps, (B, ne, D), gmd, r, landing
+        if landing is not None:
+            landing.mesh_pending = True
         return hip.gather2_rows(e3, map_a, e3.view(1, B * ne, D), map_b, M, B)
 
     @staticmethod
@@ -503,12 +524,18 @@ class MeshLatFn(torch.autograd.Function):
         _, _, inv_a, inv_fold = ctx.maps
         B, ne, D = ctx.shape
         g = g.contiguous()
-        out = torch.empty(B, ne, D, dtype=torch.float32, device=g.device)
-        hip.gather2_rows(g, inv_a, None, None, ctx.gmd, B, out=out[:, : ctx.gmd])
+        land = ctx.landing
+        shared = land is not None and land.buf is not None
+        out = land.buf if shared else torch.empty(B, ne, D, dtype=torch.float32, device=g.device)
+        h = land.head if shared else 0  # rows below `head` were written by the decoder-input gather's backward
+        hip.gather2_rows(g, inv_a[h:], None, None, ctx.gmd - h, B, out=out[:, h: ctx.gmd])
         if ctx.r > 0:
             tmp = hip.gather2_rows(g, inv_fold, None, None, B * ctx.r, B, sum_batch=True)
             hip.copy_rows(tmp.view(B, ctx.r, D), out[:, ctx.gmd:])
-        return out, None, None, None, None
+        if shared:
+            land.buf, land.mesh_pending = None, False
+            return None, None, None, None, None, None
+        return out, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------

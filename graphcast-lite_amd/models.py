@@ -40,7 +40,7 @@ from .config import (
 )
 from .create_graphs import (create_decoding_graph, create_encoding_graph, create_processing_graph,
                             create_product_graph)
-from .functional import (AssembleFn, EdgeLayout, GATLayerFn, Gather2Fn, GCNStackFn, GraphNormFn, InteractionNetFn,
+from .functional import (AssembleFn, EdgeLayout, GATLayerFn, Gather2Fn, GCNStackFn, GradLanding, GraphNormFn, InteractionNetFn,
                          LayerNormFn, MeanAggFn, MeshLatFn, MLPFn)
 from .mesh import get_hierarchy_of_triangular_meshes_for_sphere, get_mesh_lat_long, prune_mesh_to_region
 
@@ -668,9 +668,12 @@ class WeatherPrediction(nn.Module):
             f = c.fold.get(B) or self._fold_setup(c, B, X3.device)
             x_c = AssembleFn.apply(X3, self.init_grid_features, f.mstat, f.x_fold)  # [B, G+Md+r, C]
             enc_c = self.encoder.forward(X=x_c, edge_index=c.enc_graph)             # [B, G+Md+r, D]
-            mesh_lat = MeshLatFn.apply(enc_c, f.maps, M, G + c.Md, f.r)             # [B, M, D]
+            land = GradLanding(G) if kwargs.pop("_landing", False) and self._grad_landing else None
+            mesh_lat = MeshLatFn.apply(enc_c, f.maps, M, G + c.Md, f.r, land)       # [B, M, D]
             maps_dec = f.maps_dec
         else:
+            kwargs.pop("_landing", None)
+            land = None
             maps_dec = c.maps_dec
             x_c = AssembleFn.apply(X3, self.init_grid_features, c.mstat_dep)           # [B, G+Md, C]
             enc_c = self.encoder.forward(X=x_c, edge_index=c.enc_graph)                 # [B, G+Md, D]
@@ -687,7 +690,7 @@ class WeatherPrediction(nn.Module):
         else:
             processed = self.processor.forward(X=mesh_lat, edge_index=self.processing_graph,
                                                attention_threshold=attention_threshold)
-        dec_in = Gather2Fn.apply(enc_c, processed, maps_dec, G + c.U, B)            # [B, G+U, D]
+        dec_in = Gather2Fn.apply(enc_c, processed, maps_dec, G + c.U, B, land)      # [B, G+U, D]
         gcn_dec = self.decoder.graph_layer.layer_type == GraphLayerType.ConvGCN
         decoded = self.decoder.forward(X=dec_in, edge_index=c.dec_graph, **({"_out_rows": G} if gcn_dec else {}))
         out, grid_lat = (decoded if gcn_dec else decoded[:, :G, :]), enc_c[:, :G, :]
@@ -696,8 +699,9 @@ class WeatherPrediction(nn.Module):
         return out, grid_lat, processed
 
     def forward_with_latents(self, X: torch.Tensor, attention_threshold=0.0, **kwargs):
+        landing = kwargs.pop("_landing", False)
         if self._compact_eligible():
-            return self._forward_compact(X, attention_threshold, **kwargs)
+            return self._forward_compact(X, attention_threshold, _landing=landing, **kwargs)
         G = self._num_grid_nodes
         if X.dim() == 3 and X.shape[0] == 1:
             X = X.squeeze(0)  # reference: X.squeeze() with batch 1 (src/models.py:822)
@@ -726,5 +730,9 @@ class WeatherPrediction(nn.Module):
         decoded = self.decoder.forward(X=processed_features, edge_index=self.decoding_graph)
         return decoded[..., :G, :], grid_node_features, processed
 
+    _grad_landing = os.environ.get("GCL_NO_LANDING", "0") in ("0", "")
+
     def forward(self, X: torch.Tensor, attention_threshold=0.0, **kwargs):
-        return self.forward_with_latents(X, attention_threshold, **kwargs)[0]
+        # only the prediction leaves this call, so the compact encoder output has exactly two gradient consumers and
+        # they may share one gradient buffer (functional.GradLanding)
+        return self.forward_with_latents(X, attention_threshold, _landing=True, **kwargs)[0]
