@@ -333,6 +333,8 @@ def main():
         # Kernels replayed from a hipGraph cannot be bracketed by timing events on ROCm, so the
         # roofline kernel is timed on a few eager steps of the SAME step function right after the
         # timed region (same buffers, same launches; the rocprofv3 trace in profiles/ covers both).
+        for _ in range(2):  # the eager path allocates its intermediates outside the graph's pool: let the allocator settle
+            loss = step._eager(X, y)
         probe = arm_profile()
         roof_steps = max(3, min(args.steps, 10))
         torch.cuda.synchronize()
