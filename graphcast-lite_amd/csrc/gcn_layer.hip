@@ -46,6 +46,28 @@ __device__ float4 gl_zero4[1];
 
 __device__ __forceinline__ int d_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// ---- exact 3-way bf16 operand split (x3.h; the same arithmetic as linear_x3.hip) ----
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+struct Pk3 {
+  unsigned h, m, l;
+};
+__device__ __forceinline__ Pk3 split2(float a, float b) {
+  Pk3 p;
+  p.h = pk_bf16(a, b);
+  float ra = a - __uint_as_float(p.h << 16), rb = b - __uint_as_float(p.h & 0xffff0000u);
+  p.m = pk_bf16(ra, rb);
+  ra -= __uint_as_float(p.m << 16);
+  rb -= __uint_as_float(p.m & 0xffff0000u);
+  p.l = pk_bf16(ra, rb);
+  return p;
+}
+constexpr int kWRowB = 144;  // bytes per row of a weight piece image: 64 bf16 + 16 (conflict-free ds_read_b128 fragments)
+
 template <int ACT>
 __device__ __forceinline__ float act_t(float x, float a) {
   if (ACT == gcl::kActPrelu) return x > 0.f ? x : a * x;
@@ -361,11 +383,93 @@ __device__ __forceinline__ void mfma_tile(f32x16 (&acc)[NS], const float* __rest
   }
 }
 
+// Weight piece images for the split-operand MFMA: Wimg[p][j][k] (p = hi | mid | lo) = piece p of W[j][k], rows of
+// kWRowB bytes; block-cooperative, 8 loads in flight per thread.
+__device__ __forceinline__ void stage_panel_x3(unsigned char* Wimg, const float* __restrict__ W, int N, int K, int NJ32) {
+  const int NT = blockDim.x, tid = threadIdx.x;
+  const int total = NJ32 * 32;  // (row, k-pair)
+  const int pieceB = NJ32 * kWRowB;
+  for (int base = 0; base < total; base += NT * 4) {
+    float2 wv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * NT + tid;
+      const int j = idx >> 5, k = (idx & 31) * 2;
+      const bool ok = idx < total && j < N;
+      wv[u].x = (ok && k < K) ? W[(int64_t)j * K + k] : 0.f;
+      wv[u].y = (ok && k + 1 < K) ? W[(int64_t)j * K + k + 1] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * NT + tid;
+      if (idx < total) {
+        const int j = idx >> 5, k = (idx & 31) * 2;
+        const Pk3 p = split2(wv[u].x, wv[u].y);
+        unsigned char* d = Wimg + j * kWRowB + k * 2;
+        *reinterpret_cast<unsigned*>(d) = p.h;
+        *reinterpret_cast<unsigned*>(d + pieceB) = p.m;
+        *reinterpret_cast<unsigned*>(d + 2 * pieceB) = p.l;
+      }
+    }
+  }
+}
+
+// acc[c] += At[32][K] x W[c*32..+31][K]^T on the bf16 pipe (x3.h): the fp32 tile is read in the bf16 operand layout
+// (lane (r, h): 8 consecutive k of row r = four 8-byte reads, conflict-free on the KP = K + 2 stride), split in
+// registers into hi / mid / lo fragments, and multiplied with the weight piece fragments (ds_read_b128) in three
+// passes, smallest products first.  K % 16 == 0.
+template <int NS>
+__device__ __forceinline__ void mfma_tile_x3(f32x16 (&acc)[NS], const float* __restrict__ At, int KP,
+                                             const unsigned char* __restrict__ Wimg, int nks) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const float* ap = At + r * KP + 8 * h;
+  const int pieceB = NS * 32 * kWRowB;
+  const unsigned char* wp = Wimg + r * kWRowB + h * 16;
+  bf16x8 ah[4], am[4], al[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (s < nks) {
+      const float2 f0 = *reinterpret_cast<const float2*>(ap + 16 * s), f1 = *reinterpret_cast<const float2*>(ap + 16 * s + 2);
+      const float2 f2 = *reinterpret_cast<const float2*>(ap + 16 * s + 4), f3 = *reinterpret_cast<const float2*>(ap + 16 * s + 6);
+      const Pk3 p0 = split2(f0.x, f0.y), p1 = split2(f1.x, f1.y), p2 = split2(f2.x, f2.y), p3 = split2(f3.x, f3.y);
+      typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+      ah[s] = __builtin_bit_cast(bf16x8, u32x4_t{p0.h, p1.h, p2.h, p3.h});
+      am[s] = __builtin_bit_cast(bf16x8, u32x4_t{p0.m, p1.m, p2.m, p3.m});
+      al[s] = __builtin_bit_cast(bf16x8, u32x4_t{p0.l, p1.l, p2.l, p3.l});
+    }
+  }
+  auto wfrag = [&](int c, int s, int p) {
+    return *reinterpret_cast<const bf16x8*>(wp + p * pieceB + c * 32 * kWRowB + s * 32);
+  };
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    if (s < nks)
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], wfrag(c, s, 0), acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], wfrag(c, s, 2), acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[s], wfrag(c, s, 1), acc[c], 0, 0, 0);
+      }
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    if (s < nks)
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[s], wfrag(c, s, 0), acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], wfrag(c, s, 1), acc[c], 0, 0, 0);
+      }
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    if (s < nks)
+#pragma unroll
+      for (int c = 0; c < NS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], wfrag(c, s, 0), acc[c], 0, 0, 0);
+}
+
 // Transpose the 32 x (NS*32) accumulator tile through the wave's LDS region Ot[32][NS*32] and write whole
 // 16-byte row segments:  Y[r0 + i][0 .. Nst) (rows >= nr and columns >= Nst dropped by the range check).
 template <int NS>
 __device__ __forceinline__ void store_tile(const f32x16 (&acc)[NS], float* __restrict__ Ot, float* Ybase, int64_t ldy,
-                                           int nr, int Nst) {
+                                           int nr, int Nst, float4 bq = make_float4(0.f, 0.f, 0.f, 0.f)) {
   constexpr int OS = NS * 32;          // floats per staged row
   constexpr int LPO = OS / 4;          // lanes per row (8 or 16)
   constexpr int RPP = 64 / LPO;        // rows per pass
@@ -379,7 +483,8 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[NS], float* __res
 #pragma unroll
   for (int p = 0; p < 32 / RPP; ++p) {
     const int i = p * RPP + orow;
-    const float4 v = *reinterpret_cast<const float4*>(Ot + i * OS + ocol);
+    float4 v = *reinterpret_cast<const float4*>(Ot + i * OS + ocol);
+    v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;  // (zero unless the bias was kept out of the accumulator)
     buf_st4(ry, (ocol < Nst) ? (unsigned)((i * ldy + ocol) * 4) : kOOB, v);
   }
 }
@@ -402,7 +507,9 @@ __device__ unsigned long long gl_stamps[8 * 4096];  // diagnostic builds only (m
 // floats of one wave's LDS region
 __host__ __device__ constexpr int wave_region_f(int tile_f) { return tile_f + kSinkF + kMetaF; }
 
-template <int NS, int ACT, int EW, int NW, bool SAFE>
+// X3: the dense part runs on the bf16 matrix pipe with exact 3-way operand splitting (fp32 accuracy, 0.375x the matrix
+// time, and - unlike the fp32-operand MFMA - it leaves the SIMD's issue port to the other waves' gathers meanwhile).
+template <int NS, int ACT, int EW, int NW, bool SAFE, bool X3>
 __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void gcn_fwd_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ w,
     const int32_t* __restrict__ ecol, const float* __restrict__ ew, const float* __restrict__ X, int64_t ldx,
@@ -411,19 +518,27 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void gcn_fwd_kernel(
     int32_t nRT) {
   extern __shared__ __align__(16) float smem[];
   const int KP = K + 2;  // K % 4 == 0: even stride with KP/2 odd -> conflict-free 8-byte fragment reads
-  float* Wl = smem;      // [NS*32][KP]
+  float* Wl = smem;      // fp32: [NS*32][KP]; X3: three bf16 piece images [NS*32][kWRowB bytes]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int TILE_F = 32 * (KP > NS * 32 ? KP : NS * 32);  // the [32][KP] tile, reused as the [32][NS*32] output staging
-  float* At = smem + (size_t)NS * 32 * KP + (size_t)wave * wave_region_f(TILE_F);
+  const size_t panel_f = X3 ? (size_t)3 * NS * 32 * kWRowB / 4 : (size_t)NS * 32 * KP;
+  float* At = smem + panel_f + (size_t)wave * wave_region_f(TILE_F);
   float* Sink = At + TILE_F;
   float* Mt = Sink + kSinkF;
-  stage_panel<false>(Wl, W, K, N, K, NS * 32, K, KP);
+  if (X3) stage_panel_x3(reinterpret_cast<unsigned char*>(Wl), W, N, K, NS * 32);
+  else stage_panel<false>(Wl, W, K, N, K, NS * 32, K, KP);
   const float slope = (ACT == gcl::kActPrelu) ? *slope_p : 1.f;
   float bj[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int j = s * 32 + (lane & 31);
-    bj[s] = (bias && j < N) ? bias[j] : 0.f;
+    bj[s] = (bias && j < N && !X3) ? bias[j] : 0.f;
+  }
+  float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);  // X3: the bias of the four columns this lane stores, added after the transpose
+  if (X3 && bias) {
+    const int oc = (lane % (NS * 8)) * 4;
+    bq.x = oc < N ? bias[oc] : 0.f; bq.y = oc + 1 < N ? bias[oc + 1] : 0.f;
+    bq.z = oc + 2 < N ? bias[oc + 2] : 0.f; bq.w = oc + 3 < N ? bias[oc + 3] : 0.f;
   }
   __syncthreads();  // the only block barrier: from here on every wave works on its own LDS region
 
@@ -468,12 +583,13 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void gcn_fwd_kernel(
     for (int s = 0; s < NS; ++s)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][r] = bj[s];  // the bias rides in the accumulator's initial value
-    mfma_tile<NS>(acc, At, Wl, KP, K >> 2);
+    if (X3) mfma_tile_x3<NS>(acc, At, KP, reinterpret_cast<const unsigned char*>(Wl), K >> 4);
+    else mfma_tile<NS>(acc, At, Wl, KP, K >> 2);
 #ifdef GCL_STAMPS
     asm volatile("" ::"v"(acc[0][0]));
 #endif
     GCL_STAMP(3);
-    store_tile<NS>(acc, At, Y + (int64_t)b * bsy + (int64_t)r0 * ldy, ldy, n - r0 < 32 ? n - r0 : 32, Nst);
+    store_tile<NS>(acc, At, Y + (int64_t)b * bsy + (int64_t)r0 * ldy, ldy, n - r0 < 32 ? n - r0 : 32, Nst, bq);
     GCL_STAMP(4);
     b = bn;
     r0 = rn;
@@ -520,20 +636,31 @@ extern "C" int gcl_gcn_layer_fwd(const gcl_graph_t* g, const float* x, int64_t l
   const int32_t n = g->n;
   const int32_t nRT = (int32_t)gcl::cdiv(n, 32);
   const int NS = Fout_store > 32 ? 2 : 1;
-  constexpr int NW = 12;
+  constexpr int NW12 = 12, NW8 = 8;
   const int KP = Fin + 2;
-  const size_t lds = ((size_t)NS * 32 * KP + (size_t)NW * wave_region_f(32 * (KP > NS * 32 ? KP : NS * 32))) * sizeof(float);
+  static const int x3_env = env_int("GCL_X3", 1) && env_int("GCL_X3_GCN", 1);
+  const size_t wave1_b = (size_t)wave_region_f(32 * (KP > NS * 32 ? KP : NS * 32)) * sizeof(float);
+  // the split-operand variant holds its A fragments in registers: 8 waves per block (256 VGPRs each) instead of 12
+  const bool x3 = x3_env != 0 && (Fin % 16 == 0);
+  const int NWr = x3 ? NW8 : NW12;
+  const size_t lds = (x3 ? (size_t)3 * NS * 32 * kWRowB : (size_t)NS * 32 * KP * sizeof(float)) + NWr * wave1_b;
   GCL_CHECK_ARG((int64_t)n * ldx * 4 < (int64_t)1 << 31 && n < (1 << 24) && ldx * 4 < (1 << 24),
                 "gcn_layer_fwd: one sample of x must stay below 2 GiB (n, row bytes < 2^24)");
   const int64_t tiles = (int64_t)B * nRT;
   int64_t grid = gcl::kNumCU;
-  if (tiles < grid * NW) grid = gcl::cdiv(tiles, NW);
+  if (tiles < grid * NWr) grid = gcl::cdiv(tiles, NWr);
   if (B >= gcl::kNumXCD) grid = gcl::cdiv(grid, gcl::kNumXCD) * gcl::kNumXCD;  // XCD-aware schedule needs a multiple of 8
   const int ewidth = g->ell_cover;  // smallest prefix width that covers (almost) every row: the fix-up loop is the slow path
   hipStream_t st = (hipStream_t)stream;
-#define GCL_GF4(NS_, ACT_, EW_)                                                                                      \
+#define GCL_GF4(NS_, ACT_, EW_)                \
+  do {                                         \
+    if (x3) GCL_GF5(NS_, ACT_, EW_, true);     \
+    else GCL_GF5(NS_, ACT_, EW_, false);       \
+  } while (0)
+#define GCL_GF5(NS_, ACT_, EW_, X3_)                                                                                 \
   do {                                                                                                              \
-    auto kern = gcn_fwd_kernel<NS_, ACT_, EW_, NW, false>;                                                                  \
+    constexpr int NW = X3_ ? NW8 : NW12;                                                                            \
+    auto kern = gcn_fwd_kernel<NS_, ACT_, EW_, NW, false, X3_>;                                                              \
     { static bool lds_set = false;                                                                                   \
       if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, st, g->rowptr, g->col, g->w, g->ecol, g->ew, x, \
@@ -555,13 +682,18 @@ extern "C" int gcl_gcn_layer_fwd(const gcl_graph_t* g, const float* x, int64_t l
   } while (0)
   if (g->kind == GCL_GRAPH_MEAN) {  // no self-loops: masked (SAFE) variant, activation-free, widest prefix
     GCL_CHECK_ARG(act == GCL_ACT_NONE, "gcn_layer_fwd: mean-aggregation graphs take no activation");
+    constexpr int NW = NW12;
+    const size_t lds = (size_t)NS * 32 * KP * sizeof(float) + NW * wave1_b;
+    int64_t grid = gcl::kNumCU;
+    if (tiles < grid * NW) grid = gcl::cdiv(tiles, NW);
+    if (B >= gcl::kNumXCD) grid = gcl::cdiv(grid, gcl::kNumXCD) * gcl::kNumXCD;
     if (NS == 2) {
-      auto kern = gcn_fwd_kernel<2, gcl::kActNone, 8, NW, true>;
+      auto kern = gcn_fwd_kernel<2, gcl::kActNone, 8, NW, true, false>;
       GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, st, g->rowptr, g->col, g->w, g->ecol, g->ew, x, ldx,
                          bsx, slope, W, bias, y, ldy, bsy, n, B, Fin, Fout, Fout_store, nRT);
     } else {
-      auto kern = gcn_fwd_kernel<1, gcl::kActNone, 8, NW, true>;
+      auto kern = gcn_fwd_kernel<1, gcl::kActNone, 8, NW, true, false>;
       GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, st, g->rowptr, g->col, g->w, g->ecol, g->ew, x, ldx,
                          bsx, slope, W, bias, y, ldy, bsy, n, B, Fin, Fout, Fout_store, nRT);
@@ -571,6 +703,7 @@ extern "C" int gcl_gcn_layer_fwd(const gcl_graph_t* g, const float* x, int64_t l
 #undef GCL_GF2
 #undef GCL_GF3
 #undef GCL_GF4
+#undef GCL_GF5
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }
