@@ -515,7 +515,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void gcn_fwd_kernel(
     const int32_t* __restrict__ ecol, const float* __restrict__ ew, const float* __restrict__ X, int64_t ldx,
     int64_t bsx, const float* __restrict__ slope_p, const float* __restrict__ W, const float* __restrict__ bias,
     float* __restrict__ Y, int64_t ldy, int64_t bsy, int32_t n, int32_t B, int32_t K, int32_t N, int32_t Nst,
-    int32_t nRT) {
+    int32_t nRT, int32_t n_out) {
   extern __shared__ __align__(16) float smem[];
   const int KP = K + 2;  // K % 4 == 0: even stride with KP/2 odd -> conflict-free 8-byte fragment reads
   float* Wl = smem;      // fp32: [NS*32][KP]; X3: three bf16 piece images [NS*32][kWRowB bytes]
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void gcn_fwd_kernel(
     asm volatile("" ::"v"(acc[0][0]));
 #endif
     GCL_STAMP(3);
-    store_tile<NS>(acc, At, Y + (int64_t)b * bsy + (int64_t)r0 * ldy, ldy, n - r0 < 32 ? n - r0 : 32, Nst, bq);
+    store_tile<NS>(acc, At, Y + (int64_t)b * bsy + (int64_t)r0 * ldy, ldy, n_out - r0 < 32 ? n_out - r0 : 32, Nst, bq);
     GCL_STAMP(4);
     b = bn;
     r0 = rn;
@@ -621,6 +621,14 @@ extern "C" int gcl_gcn_layer_fwd(const gcl_graph_t* g, const float* x, int64_t l
                                  const float* slope, const float* W, const float* bias, float* y, int64_t ldy,
                                  int64_t bsy, int32_t B, int32_t Fin, int32_t Fout, int32_t Fout_store,
                                  gcl_stream_t stream) {
+  return gcl_gcn_layer_fwd_rows(g, x, ldx, bsx, act, slope, W, bias, y, ldy, bsy, B, Fin, Fout, Fout_store,
+                                g ? g->n : 0, stream);
+}
+
+extern "C" int gcl_gcn_layer_fwd_rows(const gcl_graph_t* g, const float* x, int64_t ldx, int64_t bsx, int32_t act,
+                                      const float* slope, const float* W, const float* bias, float* y, int64_t ldy,
+                                      int64_t bsy, int32_t B, int32_t Fin, int32_t Fout, int32_t Fout_store,
+                                      int32_t rows_out, gcl_stream_t stream) {
   GCL_CHECK_ARG(g && x && W && y, "gcn_layer_fwd: null argument");
   GCL_CHECK_ARG(g->kind == GCL_GRAPH_GCN || g->kind == GCL_GRAPH_MEAN, "gcn_layer_fwd: graph carries no edge weights");
   GCL_CHECK_ARG(B > 0 && Fin >= 4 && Fin <= 64 && Fin % 4 == 0 && Fout >= 1 && Fout <= 64,
@@ -634,7 +642,8 @@ extern "C" int gcl_gcn_layer_fwd(const gcl_graph_t* g, const float* x, int64_t l
                 "gcn_layer_fwd: bad activation %d", act);
   GCL_CHECK_ARG(x != y, "gcn_layer_fwd: in-place is not supported");
   const int32_t n = g->n;
-  const int32_t nRT = (int32_t)gcl::cdiv(n, 32);
+  GCL_CHECK_ARG(rows_out >= 1 && rows_out <= n, "gcn_layer_fwd: rows_out=%d outside [1, n=%d]", rows_out, n);
+  const int32_t nRT = (int32_t)gcl::cdiv(rows_out, 32);  // only the tiles that hold requested rows are computed
   const int NS = Fout_store > 32 ? 2 : 1;
   constexpr int NW12 = 12, NW8 = 8;
   const int KP = Fin + 2;
@@ -664,7 +673,7 @@ extern "C" int gcl_gcn_layer_fwd(const gcl_graph_t* g, const float* x, int64_t l
     { static bool lds_set = false;                                                                                   \
       if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, st, g->rowptr, g->col, g->w, g->ecol, g->ew, x, \
-                       ldx, bsx, slope, W, bias, y, ldy, bsy, n, B, Fin, Fout, Fout_store, nRT);                     \
+                       ldx, bsx, slope, W, bias, y, ldy, bsy, n, B, Fin, Fout, Fout_store, nRT, rows_out);                     \
   } while (0)
 #define GCL_GF3(NS_, ACT_)                  \
   do {                                      \
@@ -691,12 +700,12 @@ extern "C" int gcl_gcn_layer_fwd(const gcl_graph_t* g, const float* x, int64_t l
       auto kern = gcn_fwd_kernel<2, gcl::kActNone, 8, NW, true, false>;
       GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, st, g->rowptr, g->col, g->w, g->ecol, g->ew, x, ldx,
-                         bsx, slope, W, bias, y, ldy, bsy, n, B, Fin, Fout, Fout_store, nRT);
+                         bsx, slope, W, bias, y, ldy, bsy, n, B, Fin, Fout, Fout_store, nRT, rows_out);
     } else {
       auto kern = gcn_fwd_kernel<1, gcl::kActNone, 8, NW, true, false>;
       GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, st, g->rowptr, g->col, g->w, g->ecol, g->ew, x, ldx,
-                         bsx, slope, W, bias, y, ldy, bsy, n, B, Fin, Fout, Fout_store, nRT);
+                         bsx, slope, W, bias, y, ldy, bsy, n, B, Fin, Fout, Fout_store, nRT, rows_out);
     }
   } else if (NS == 2) GCL_GF2(2);
   else GCL_GF2(1);

@@ -123,6 +123,7 @@ class MLPFn(torch.autograd.Function):
 # params layout: [W1, b1, ..., WL, bL, slope] (+ [gamma, beta]);  slope may be None when L == 1
 # ------------------------------------------------------------------------------------------------
 _LN_COLSUM = os.environ.get("GCL_NO_LN_COLSUM", "0") in ("0", "")
+_ROWS_OUT = os.environ.get("GCL_NO_ROWS_OUT", "0") in ("0", "")
 
 
 class GCNStackFn(torch.autograd.Function):
@@ -151,7 +152,9 @@ class GCNStackFn(torch.autograd.Function):
                 # ONE kernel (csrc/gcn_layer.hip): gather-aggregate the activated input rows, then the dense
                 # transform; an output width that is not a multiple of 4 (33 / 19 variables) is stored ldh wide
                 # with zero padding columns, so the layer and its backward stay on 16-byte rows
-                p = hip.gcn_layer_fwd(graph, cur, act_k, slope_k, W, b)
+                # the last conv of a stack whose caller keeps only the first rows (decoder: grid rows) computes only those
+                last_rows = int(out_rows) if (k == L - 1 and out_rows and out_rows < n and not has_ln and _ROWS_OUT) else None
+                p = hip.gcn_layer_fwd(graph, cur, act_k, slope_k, W, b, rows_out=last_rows)
                 if k == L - 1 and ldh != Fout and not has_ln:
                     pad_last = (ldh, Fout, None)
                 elif ldh != Fout:

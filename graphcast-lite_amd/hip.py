@@ -76,6 +76,7 @@ _SIGNATURES = {
     "gcl_dense_bwd_dw": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp,
                                    C.c_size_t, _vp]),
     "gcl_gcn_layer_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "gcl_gcn_layer_fwd_rows": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "gcl_segment_reduce": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "gcl_edge_combine": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i32, _i64, _i32, _vp]),
     "gcl_act_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
@@ -726,9 +727,10 @@ def gcn_layer_fusable(graph: Graph, x3, Fin: int, Fout: int) -> bool:
             and x3.stride(2) == 1 and x3.stride(1) % 4 == 0 and x3.stride(0) % 4 == 0 and x3.data_ptr() % 16 == 0)
 
 
-def gcn_layer_fwd(graph: Graph, x3, act, slope, W, bias, out=None):
+def gcn_layer_fwd(graph: Graph, x3, act, slope, W, bias, out=None, rows_out=None):
     """y = (A_hat act(x)) W^T + bias for x3 [B, n, Fin] -> [B, n, Fout] (one kernel).  The result is a view of
-    a [B, n, roundup(Fout, 4)] buffer whose padding columns are zero."""
+    a [B, n, roundup(Fout, 4)] buffer whose padding columns are zero.  rows_out: only the first rows_out rows of every
+    sample are computed (the others stay unwritten)."""
     B, n, Fin = x3.shape
     assert n == graph.n
     Fout = W.shape[0]
@@ -737,7 +739,8 @@ def gcn_layer_fwd(graph: Graph, x3, act, slope, W, bias, out=None):
         out = torch.empty(B, n, Fst, dtype=torch.float32, device=x3.device)
     assert out.shape[2] >= Fst or out.stride(1) >= Fst
     tok = _probe_begin("gcn_layer_fwd", graph=graph, B=B, Fin=Fin, Fout=Fout)
-    _check(lib().gcl_gcn_layer_fwd(graph.handle, _p(x3), x3.stride(1), x3.stride(0), int(act), _p(slope), _p(W.contiguous()),
-                                   _p(bias), _p(out), out.stride(1), out.stride(0), B, Fin, Fout, Fst, _stream()))
+    _check(lib().gcl_gcn_layer_fwd_rows(graph.handle, _p(x3), x3.stride(1), x3.stride(0), int(act), _p(slope),
+                                        _p(W.contiguous()), _p(bias), _p(out), out.stride(1), out.stride(0), B, Fin, Fout,
+                                        Fst, int(rows_out) if rows_out else n, _stream()))
     _probe_end(tok)
     return out[..., :Fout]

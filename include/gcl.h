@@ -310,6 +310,12 @@ int gcl_gcn_layer_fwd(const gcl_graph_t* g, const float* x, int64_t ldx, int64_t
                       const float* slope, const float* W /*[Fout,Fin]*/, const float* bias, float* y,
                       int64_t ldy, int64_t bsy, int32_t B, int32_t Fin, int32_t Fout, int32_t Fout_store,
                       gcl_stream_t stream);
+/* Same, computing only the first rows_out rows of every sample (rows beyond are not written): the decoder keeps
+ * only the grid rows of its last conv (src/models.py:870-872), whose mesh rows are dead. */
+int gcl_gcn_layer_fwd_rows(const gcl_graph_t* g, const float* x, int64_t ldx, int64_t bsx, int32_t act,
+                           const float* slope, const float* W /*[Fout,Fin]*/, const float* bias, float* y,
+                           int64_t ldy, int64_t bsy, int32_t B, int32_t Fin, int32_t Fout, int32_t Fout_store,
+                           int32_t rows_out, gcl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Edge-wise glue of the InteractionNet processor (src/models.py:206-236); csrc/interaction.hip.
