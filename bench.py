@@ -309,6 +309,11 @@ def main():
         hip.PROBE = LaunchProbe(match)
         return hip.PROBE
 
+    bufs = step.input_buffers()
+    if bufs is not None:  # the synthetic batch lives in the buffers the captured graph reads (a loader would fill them in place)
+        bufs[0].copy_(X)
+        bufs[1].copy_(y)
+        X, y = bufs
     probe = None
     replayed = step.graph_active
     if not replayed:

@@ -494,6 +494,16 @@ class TrainStep:
             return self._replay()  # capture only records; the first replay performs this step
         if X.shape != self._sX.shape:
             return self._eager(X, y, threshold, epoch, batch_num)
-        self._sX.copy_(X)
-        self._sy.copy_(y)
+        # a producer that fills input_buffers() in place passes those tensors back and saves the two device copies
+        if X.data_ptr() != self._sX.data_ptr():
+            self._sX.copy_(X)
+        if y.data_ptr() != self._sy.data_ptr():
+            self._sy.copy_(y)
         return self._replay()
+
+    def input_buffers(self):
+        """(X, y) the captured graph reads its batch from, or None before the capture / on the eager path: fill them
+        in place and pass them to the step to skip its per-step copy of the batch."""
+        if self.use_graph and self._graph is not None:
+            return self._sX, self._sy
+        return None
