@@ -74,13 +74,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ X
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma;  partial dgamma/dbeta per block
 // CS: also the column sums of dX (the bias gradient of the layer below: dX is that layer's dY) as a third vector
-template <int LPR, bool V, bool CS>
+__device__ __attribute__((aligned(16))) float ln_zero_row[256];  // what an unmapped row reads
+
+// MAP: dY is given through a row map instead of densely - row (b, i) of the [B][n] row space reads
+// dY[b * bsdy + pos[i] * lddy] when pos[i] >= 0 and is zero otherwise (the gradient of a layer whose output was only
+// consumed through a row gather: no zero-filled dense gradient has to exist).
+template <int LPR, bool V, bool CS, bool MAP>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dY, int64_t lddy,
                                                      const float* __restrict__ X, int64_t ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ stats,
                                                      float* __restrict__ dX, int64_t lddx, float* __restrict__ part,
                                                      int64_t rows, int32_t F, int32_t FP, int32_t vdy, int32_t vx,
-                                                     int32_t vdx) {
+                                                     int32_t vdx, const int32_t* __restrict__ pos, int64_t bsdy,
+                                                     int32_t n_per) {
   if (V) vdy = vx = vdx = 1;
   constexpr int RPW = 64 / LPR;
   constexpr int RPB = RPW * 4;
@@ -93,12 +99,39 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   if (c0 < F) load4(gamma + c0, c0, F, false, g0, g1, g2, g3);
   float dg0 = 0, dg1 = 0, dg2 = 0, dg3 = 0, db0 = 0, db1 = 0, db2 = 0, db3 = 0;
   float cs0 = 0, cs1 = 0, cs2 = 0, cs3 = 0;
-  for (int64_t row = (int64_t)blockIdx.x * RPB + wave * RPW + sub; row < rows; row += (int64_t)gridDim.x * RPB) {
+  // MAP: (sample, row in sample) of this lane group's row, advanced with the grid stride (no division per row)
+  const int64_t row_first = (int64_t)blockIdx.x * RPB + wave * RPW + sub, row_step = (int64_t)gridDim.x * RPB;
+  int64_t mb = 0, msb = 0;
+  int mi = 0, msi = 0;
+  int pj = -1;  // map entry of the CURRENT row, fetched one iteration ahead (its load -> the row load is a dependent pair)
+  if (MAP) {
+    mb = row_first / n_per;
+    mi = (int)(row_first - mb * n_per);
+    msb = row_step / n_per;
+    msi = (int)(row_step - msb * n_per);
+    if (row_first < rows) pj = pos[mi];
+  }
+  for (int64_t row = row_first; row < rows; row += row_step) {
     float x0 = 0, x1 = 0, x2 = 0, x3 = 0, y0 = 0, y1 = 0, y2 = 0, y3 = 0;
+    int pj_next = -1;
+    int64_t mb_cur = mb;
+    if (MAP) {
+      mi += msi;
+      mb += msb;
+      if (mi >= n_per) { mi -= n_per; ++mb; }
+      if (row + row_step < rows) pj_next = pos[mi];
+    }
     if (c0 < F) {
       load4(X + row * ldx + c0, c0, F, vx, x0, x1, x2, x3);
-      load4(dY + row * lddy + c0, c0, F, vdy, y0, y1, y2, y3);
+      if (MAP) {
+        // unconditional load (pointer select): a branch around the load would serialise the row's loads (vmcnt(0))
+        const float* src = pj >= 0 ? dY + mb_cur * bsdy + (int64_t)pj * lddy + c0 : ln_zero_row + c0;
+        load4(src, c0, F, vdy, y0, y1, y2, y3);
+      } else {
+        load4(dY + row * lddy + c0, c0, F, vdy, y0, y1, y2, y3);
+      }
     }
+    pj = pj_next;
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
     const float h0 = (c0 < F) ? (x0 - mean) * rstd : 0.f, h1 = (c0 + 1 < F) ? (x1 - mean) * rstd : 0.f;
     const float h2 = (c0 + 2 < F) ? (x2 - mean) * rstd : 0.f, h3 = (c0 + 3 < F) ? (x3 - mean) * rstd : 0.f;
@@ -214,7 +247,16 @@ extern "C" int gcl_layernorm_bwd_cs(const float* dy, int64_t lddy, const float* 
                                     const float* stats, float* dx, int64_t lddx, float* dgamma, float* dbeta,
                                     float* colsum_dx, int32_t accumulate, int64_t rows, int32_t F, void* ws,
                                     size_t ws_bytes, gcl_stream_t stream) {
+  return gcl_layernorm_bwd_map(dy, lddy, 0, nullptr, 0, x, ldx, gamma, stats, dx, lddx, dgamma, dbeta, colsum_dx, accumulate,
+                               rows, F, ws, ws_bytes, stream);
+}
+
+extern "C" int gcl_layernorm_bwd_map(const float* dy, int64_t lddy, int64_t bsdy, const int32_t* pos, int32_t n_per,
+                                     const float* x, int64_t ldx, const float* gamma, const float* stats, float* dx,
+                                     int64_t lddx, float* dgamma, float* dbeta, float* colsum_dx, int32_t accumulate,
+                                     int64_t rows, int32_t F, void* ws, size_t ws_bytes, gcl_stream_t stream) {
   GCL_CHECK_ARG(dy && x && gamma && stats && dx && dgamma && dbeta, "layernorm_bwd: null argument");
+  GCL_CHECK_ARG(!pos || (n_per > 0 && rows % n_per == 0), "layernorm_bwd: mapped dy needs rows = B * n_per");
   GCL_CHECK_ARG(F >= 1 && F <= 256 && ldx >= F && lddy >= F && lddx >= F, "layernorm_bwd: bad shape F=%d", F);
   GCL_CHECK_ARG(ws && ws_bytes >= gcl_layernorm_bwd_ws_bytes(rows, F), "layernorm_bwd: workspace too small");
   if (rows == 0) return GCL_OK;
@@ -225,12 +267,17 @@ extern "C" int gcl_layernorm_bwd_cs(const float* dy, int64_t lddy, const float* 
   int64_t nb = gcl::cdiv(rows, rpb);
   if (nb > kNormBlocks) nb = kNormBlocks;
   float* part = (float*)ws;
-  const int vdy = vec_ok(dy, lddy, F), vx = vec_ok(x, ldx, F), vdx = vec_store_ok(dx, lddx, F);
+  const int vdy = vec_ok(dy, lddy, F) && (bsdy % 4 == 0), vx = vec_ok(x, ldx, F), vdx = vec_store_ok(dx, lddx, F);
   // dgamma / dbeta share GCL_ACC_DW, the column sums have their own bit (they belong to another parameter)
   const int acc_p = (accumulate & GCL_ACC_DW) ? 1 : 0, acc_cs = (accumulate & GCL_ACC_COLSUM) ? 1 : 0;
-#define CALL3(L, V_, CS_)                                                                                        \
-  hipLaunchKernelGGL((ln_bwd_kernel<L, V_, CS_>), dim3((unsigned)nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma, \
-                     stats, dx, lddx, part, rows, F, FP, vdy, vx, vdx)
+#define CALL4(L, V_, CS_, MAP_)                                                                                       \
+  hipLaunchKernelGGL((ln_bwd_kernel<L, V_, CS_, MAP_>), dim3((unsigned)nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma, \
+                     stats, dx, lddx, part, rows, F, FP, vdy, vx, vdx, pos, bsdy, n_per)
+#define CALL3(L, V_, CS_)            \
+  do {                               \
+    if (pos) CALL4(L, V_, CS_, true); \
+    else CALL4(L, V_, CS_, false);   \
+  } while (0)
 #define CALL(L)                                     \
   if (vdy && vx && vdx) {                           \
     if (colsum_dx) CALL3(L, true, true);            \
@@ -242,6 +289,7 @@ extern "C" int gcl_layernorm_bwd_cs(const float* dy, int64_t lddy, const float* 
   GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
 #undef CALL3
+#undef CALL4
   GCL_CHECK_LAUNCH();
   if (!colsum_dx) return gcl::launch_reduce_parts2(part, (int)nb, 2 * FP, FP, FP, dgamma, dbeta, F, acc_p, st);
   return gcl::launch_reduce_parts3(part, (int)nb, 3 * FP, FP, dgamma, acc_p, dbeta, acc_p, colsum_dx, acc_cs, F, st);

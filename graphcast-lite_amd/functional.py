@@ -184,6 +184,13 @@ class GCNStackFn(torch.autograd.Function):
             o2, stats = hip.layernorm_fwd(cur.view(B * n, -1), params[-2].detach(), params[-1].detach(), eps)
             out = o2.view(B, n, -1)
         ctx.owner, ctx.graph, ctx.L, ctx.has_ln = owner, graph, L, has_ln
+        ctx.land = getattr(owner, "_grad_src", None)
+        if ctx.land is not None:
+            owner._grad_src = None
+            if has_ln and not (out_rows and out_rows < n) and not squeeze:
+                ctx.land.proc_ready = True
+            else:
+                ctx.land = None
         ctx.x3, ctx.ps, ctx.stats, ctx.params, ctx.squeeze = x3, ps, stats, params, squeeze
         ctx.n_rows, ctx.out_rows = n, (int(out_rows) if out_rows and out_rows < n else 0)
         if ctx.out_rows:
@@ -195,7 +202,16 @@ class GCNStackFn(torch.autograd.Function):
         params, L, graph = ctx.params, ctx.L, ctx.graph
         needs = list(ctx.needs_input_grad[7:])
         G = _Grads(list(params), needs)
-        dy3 = _flat3(dy)
+        land = ctx.land
+        dy_map = None
+        if land is not None and land.proc_src is not None:
+            # the incoming `dy` is a stride-0 token: the real gradient is the gather's, read through its row map
+            dy_map = (land.proc_src, land.proc_map)
+            land.proc_src = land.proc_map = None
+            land.proc_ready = False
+            dy3 = dy
+        else:
+            dy3 = _flat3(dy)
         B, n = dy3.shape[0], ctx.n_rows
         ps = ctx.ps
         pad = ctx.pad_last
@@ -210,9 +226,9 @@ class GCNStackFn(torch.autograd.Function):
             dbet = G.dst[bi] if G.dst[bi] is not None else torch.zeros_like(params[bi])
             # the LayerNorm backward also sums its dx over the rows: that IS the bias gradient of the last conv
             cs = G.dst[bi_last] if (pad is None and _LN_COLSUM) else None
-            dp = hip.layernorm_bwd(dy3.view(B * n, -1), ps[-1].view(B * n, -1), params[gi].detach(), ctx.stats, dgam,
-                                   dbet, G.acc[gi] and G.acc[bi], colsum_dx=cs,
-                                   acc_colsum=bool(cs is not None and G.acc[bi_last])).view(B, n, -1)
+            dp = hip.layernorm_bwd(None if dy_map is not None else dy3.view(B * n, -1), ps[-1].view(B * n, -1),
+                                   params[gi].detach(), ctx.stats, dgam, dbet, G.acc[gi] and G.acc[bi], colsum_dx=cs,
+                                   acc_colsum=bool(cs is not None and G.acc[bi_last]), dy_map=dy_map).view(B, n, -1)
             cs_done = cs is not None
         else:
             dp = dy3
@@ -487,7 +503,12 @@ class Gather2Fn(torch.autograd.Function):
                 da = hip.gather2_rows(g, inv_a, None, None, ctx.sa[1], ctx.B, sum_batch=bc)
         if ctx.sb is not None and ctx.needs_input_grad[1]:
             bc = ctx.sb[0] == 1 and ctx.B > 1
-            db = hip.gather2_rows(g, inv_b, None, None, ctx.sb[1], ctx.B, sum_batch=bc)
+            land = ctx.landing
+            if land is not None and land.proc_ready and not bc:
+                land.proc_src, land.proc_map = g, inv_b
+                db = g.new_zeros(()).expand(ctx.sb)  # a stride-0 token: the consumer reads land.proc_src instead
+            else:
+                db = hip.gather2_rows(g, inv_b, None, None, ctx.sb[1], ctx.B, sum_batch=bc)
         return da, db, None, None, None, None
 
 
@@ -499,6 +520,10 @@ class GradLanding:
 
     def __init__(self, head: int):
         self.head, self.buf, self.mesh_pending = head, None, False
+        # second channel: the processor's output is only consumed by the decoder-input gather, so its gradient is the
+        # gather's incoming gradient seen through a row map - the processor's LayerNorm backward reads it that way
+        # (gcl_layernorm_bwd_map) instead of a zero-filled dense [B, M, D] tensor
+        self.proc_ready, self.proc_src, self.proc_map = False, None, None
 
 
 class MeshLatFn(torch.autograd.Function):

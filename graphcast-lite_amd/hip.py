@@ -53,6 +53,8 @@ _SIGNATURES = {
     "gcl_layernorm_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _vp, _i64, _vp, _i64, _i32, _vp]),
     "gcl_layernorm_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i64, _i32, _vp, _sz, _vp]),
     "gcl_layernorm_bwd_cs": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _sz, _vp]),
+    "gcl_layernorm_bwd_map": (C.c_int, [_vp, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i64,
+                                        _i32, _vp, _sz, _vp]),
     "gcl_layernorm_bwd_ws_bytes": (_sz, [_i64, _i32]),
     "gcl_graphnorm_fwd": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _f32, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "gcl_graphnorm_bwd": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f32, _vp, _i64, _i64, _vp, _vp,
@@ -452,14 +454,23 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y, stats
 
 
-def layernorm_bwd(dy, x, gamma, stats, dgamma, dbeta, accumulate: bool, colsum_dx=None, acc_colsum: bool = False):
+def layernorm_bwd(dy, x, gamma, stats, dgamma, dbeta, accumulate: bool, colsum_dx=None, acc_colsum: bool = False,
+                  dy_map=None):
     """dx of the node LayerNorm (+ dgamma, dbeta); `colsum_dx` also receives the column sums of dx (the bias
-    gradient of the layer below) from the same pass."""
+    gradient of the layer below) from the same pass.  dy_map = (src3 [B, m, F'], pos int32 [n]): dy is not dense -
+    row (b, i) reads src3[b, pos[i], :F] (zero where pos[i] < 0); x then holds B * n rows."""
     rows, F = x.shape
     dx = torch.empty(rows, F, dtype=torch.float32, device=x.device)
     nb = lib().gcl_layernorm_bwd_ws_bytes(rows, F)
     ws = workspace(nb, x.device)
     acc = (ACC_DW if accumulate else 0) | (ACC_COLSUM if acc_colsum else 0)
+    if dy_map is not None:
+        src3, pos = dy_map
+        assert src3.stride(2) == 1 and src3.shape[2] >= F and rows % pos.numel() == 0 and src3.shape[0] == rows // pos.numel()
+        _check(lib().gcl_layernorm_bwd_map(_p(src3), src3.stride(1), src3.stride(0), _pi(pos), pos.numel(), _p(x), _ld(x),
+                                           _p(gamma), _p(stats), _p(dx), F, _p(dgamma), _p(dbeta), _p(colsum_dx), acc, rows, F,
+                                           ws.data_ptr(), ws.numel(), _stream()))
+        return dx
     _check(lib().gcl_layernorm_bwd_cs(_p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), _p(stats), _p(dx), F, _p(dgamma),
                                       _p(dbeta), _p(colsum_dx), acc, rows, F, ws.data_ptr(), ws.numel(), _stream()))
     return dx

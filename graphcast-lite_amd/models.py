@@ -415,6 +415,7 @@ class GraphLayer(nn.Module):
                 params += [ln.weight, ln.bias]
             g = _graphs.get(edge_index, n, hip.GRAPH_GCN)
             out_rows = int(kwargs.get("_out_rows") or 0)  # the caller keeps only the first rows (decoder: grid rows)
+            self._grad_src = kwargs.get("_grad_src") if fuse_ln else None  # functional.GradLanding (picked up by GCNStackFn)
             if ln is not None and not fuse_ln:
                 X = GCNStackFn.apply(X, self, g, len(convs), False, 1e-5, 0, *params)
                 X = ln(X)
@@ -689,7 +690,8 @@ class WeatherPrediction(nn.Module):
                                                edge_attr=self._processing_edge_features)
         else:
             processed = self.processor.forward(X=mesh_lat, edge_index=self.processing_graph,
-                                               attention_threshold=attention_threshold)
+                                               attention_threshold=attention_threshold,
+                                               **({"_grad_src": land} if land is not None else {}))
         dec_in = Gather2Fn.apply(enc_c, processed, maps_dec, G + c.U, B, land)      # [B, G+U, D]
         gcn_dec = self.decoder.graph_layer.layer_type == GraphLayerType.ConvGCN
         decoded = self.decoder.forward(X=dec_in, edge_index=c.dec_graph, **({"_out_rows": G} if gcn_dec else {}))

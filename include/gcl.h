@@ -238,6 +238,14 @@ int gcl_layernorm_bwd_cs(const float* dy, int64_t lddy, const float* x, int64_t 
                          const float* stats, float* dx, int64_t lddx, float* dgamma, float* dbeta,
                          float* colsum_dx, int32_t accumulate, int64_t rows, int32_t F, void* ws,
                          size_t ws_bytes, gcl_stream_t stream);
+/* Same with dy given through a row map: the rows are B samples of n_per rows, row (b, i) reads
+ * dy[b * bsdy + pos[i] * lddy + :] when pos[i] >= 0 and a zero gradient otherwise - the output of the layer was only
+ * consumed through a row gather (the decoder reads a subset of the processor's mesh rows, src/models.py:860-862), so
+ * the zero-filled dense gradient never has to be formed.  pos == NULL: dy is dense as above. */
+int gcl_layernorm_bwd_map(const float* dy, int64_t lddy, int64_t bsdy, const int32_t* pos, int32_t n_per,
+                          const float* x, int64_t ldx, const float* gamma, const float* stats, float* dx,
+                          int64_t lddx, float* dgamma, float* dbeta, float* colsum_dx, int32_t accumulate,
+                          int64_t rows, int32_t F, void* ws, size_t ws_bytes, gcl_stream_t stream);
 size_t gcl_layernorm_bwd_ws_bytes(int64_t rows, int32_t F);
 /* PyG LayerNorm(mode="graph"): statistics over all n*F elements of each sample, eps added to the
  * std.  stats [B,2] = (mean, 1/(std+eps)). */
