@@ -74,8 +74,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ X
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma;  partial dgamma/dbeta per block
 // CS: also the column sums of dX (the bias gradient of the layer below: dX is that layer's dY) as a third vector
-__device__ __attribute__((aligned(16))) float ln_zero_row[256];  // what an unmapped row reads
-
 // MAP: dY is given through a row map instead of densely - row (b, i) of the [B][n] row space reads
 // dY[b * bsdy + pos[i] * lddy] when pos[i] >= 0 and is zero otherwise (the gradient of a layer whose output was only
 // consumed through a row gather: no zero-filled dense gradient has to exist).
@@ -103,35 +101,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   const int64_t row_first = (int64_t)blockIdx.x * RPB + wave * RPW + sub, row_step = (int64_t)gridDim.x * RPB;
   int64_t mb = 0, msb = 0;
   int mi = 0, msi = 0;
-  int pj = -1;  // map entry of the CURRENT row, fetched one iteration ahead (its load -> the row load is a dependent pair)
   if (MAP) {
     mb = row_first / n_per;
     mi = (int)(row_first - mb * n_per);
     msb = row_step / n_per;
     msi = (int)(row_step - msb * n_per);
-    if (row_first < rows) pj = pos[mi];
   }
   for (int64_t row = row_first; row < rows; row += row_step) {
     float x0 = 0, x1 = 0, x2 = 0, x3 = 0, y0 = 0, y1 = 0, y2 = 0, y3 = 0;
-    int pj_next = -1;
-    int64_t mb_cur = mb;
-    if (MAP) {
-      mi += msi;
-      mb += msb;
-      if (mi >= n_per) { mi -= n_per; ++mb; }
-      if (row + row_step < rows) pj_next = pos[mi];
-    }
     if (c0 < F) {
       load4(X + row * ldx + c0, c0, F, vx, x0, x1, x2, x3);
       if (MAP) {
-        // unconditional load (pointer select): a branch around the load would serialise the row's loads (vmcnt(0))
-        const float* src = pj >= 0 ? dY + mb_cur * bsdy + (int64_t)pj * lddy + c0 : ln_zero_row + c0;
-        load4(src, c0, F, vdy, y0, y1, y2, y3);
+        // unmapped rows issue no load at all: this kernel is bound by its load INSTRUCTIONS (a wave-instruction serves
+        // only four rows), so a dummy load for them costs more than the divergent branch around the real one
+        const int pj = pos[mi];
+        if (pj >= 0) load4(dY + mb * bsdy + (int64_t)pj * lddy + c0, c0, F, vdy, y0, y1, y2, y3);
       } else {
         load4(dY + row * lddy + c0, c0, F, vdy, y0, y1, y2, y3);
       }
     }
-    pj = pj_next;
+    if (MAP) {
+      mi += msi;
+      mb += msb;
+      if (mi >= n_per) { mi -= n_per; ++mb; }
+    }
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
     const float h0 = (c0 < F) ? (x0 - mean) * rstd : 0.f, h1 = (c0 + 1 < F) ? (x1 - mean) * rstd : 0.f;
     const float h2 = (c0 + 2 < F) ? (x2 - mean) * rstd : 0.f, h3 = (c0 + 3 < F) ? (x3 - mean) * rstd : 0.f;
