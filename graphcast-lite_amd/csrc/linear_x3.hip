@@ -297,13 +297,25 @@ __global__ __launch_bounds__(256, 2) void linear_x3_fwd_kernel(const float* __re
 // as whole 16-byte row segments.  Two block barriers per tile.
 // Partial-record layout and outputs are those of linear_bwd_fused64_kernel (linear.hip).
 // ---------------------------------------------------------------------------------------------
-constexpr int kImg64B = 64 * kRowB;  // one piece of a 64-row tile
+// Backward images: [64 rows][64 bf16] with UNPADDED 128-byte rows and the eight 16-byte chunks of row r stored at
+// chunk ^ swz(r), swz(r) = (bit1(r) << 2) | (bit3(r) << 1) | bit2(r).  One image serves both kinds of read without
+// bank conflicts: the 16 rows one ds_read_b128 cycle serves ({0-3,12-15,20-27}, ...) differ in their low four bits, so
+// (r & 1, swz(r)) - which 4-bank group of which half of the 64 banks - is distinct for all of them; and of the four
+// rows x four chunks one half-wave of ds_read_b64_tr_b16 takes, rows 0/2 (same parity) land on chunk sets that differ
+// in bit 2.  (With 144-byte padded rows a quarter of this kernel's LDS cycles were 2-way conflicts of the
+// transposing reads: profiles/r02_pmc_linear_x3.txt.)
+constexpr int kBRowB = 128;
+constexpr int kImg64B = 64 * kBRowB;  // one piece of a 64-row tile
+__device__ __forceinline__ int swz(int r) { return (((r >> 1) & 1) << 2) | (((r >> 3) & 1) << 1) | ((r >> 2) & 1); }
+// byte offset of byte `b` (< 128) of row `r`
+__device__ __forceinline__ int sw_off(int r, int b) { return r * kBRowB + ((((b >> 4) ^ swz(r)) << 4) | (b & 15)); }
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {  // rows rb..rb+3 and rb+4..rb+7 of 16 columns
+// rows rb..rb+3 (offset o0) and rb+4..rb+7 (offset o1: the swizzle differs) of 16 columns, delivered column-major
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int o0, int o1) {
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * kRowB));
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + o0));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + o1));
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -315,8 +327,8 @@ __global__ __launch_bounds__(256, 2) void linear_x3_bwd_kernel(
     double* __restrict__ part_slope) {
   constexpr int FoP = NO * 32, FiP = 64, NKO = NO * 2, NT = NO * 2;
   extern __shared__ __align__(16) unsigned char smem8[];
-  unsigned char* Yimg = smem8;                 // [3][64][kRowB]  dY pieces
-  unsigned char* Pimg = smem8 + 3 * kImg64B;   // [3][64][kRowB]  act(P) pieces
+  unsigned char* Yimg = smem8;                 // [3][64][128 B]  dY pieces (swizzled chunks)
+  unsigned char* Pimg = smem8 + 3 * kImg64B;   // [3][64][128 B]  act(P) pieces
   float* Stg = reinterpret_cast<float*>(smem8 + 6 * kImg64B);  // [64][64] fp32: dX before act'
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h = lane >> 5;
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void linear_x3_bwd_kernel(
       const int idx = i * 256 + tid;
       const int c = idx & 63, o = (idx >> 6) * 2;
       const Pk3 p = split2(wv[i].x, wv[i].y);
-      unsigned char* d = Yimg + c * kRowB + o * 2;
+      unsigned char* d = Yimg + sw_off(c, o * 2);
       *reinterpret_cast<unsigned*>(d) = p.h;
       *reinterpret_cast<unsigned*>(d + kImg64B) = p.m;
       *reinterpret_cast<unsigned*>(d + 2 * kImg64B) = p.l;
@@ -350,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void linear_x3_bwd_kernel(
     for (int s = 0; s < NKO; ++s)
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        wtf[s][p] = *reinterpret_cast<const bf16x8*>(Yimg + p * kImg64B + (32 * sg + li) * kRowB + (16 * s + 8 * h) * 2);
+        wtf[s][p] = *reinterpret_cast<const bf16x8*>(Yimg + p * kImg64B + sw_off(32 * sg + li, (16 * s + 8 * h) * 2));
     __syncthreads();
   }
 
@@ -377,9 +389,20 @@ __global__ __launch_bounds__(256, 2) void linear_x3_bwd_kernel(
   };
 
   // lane parts of the fragment addresses
-  const int fo = li * kRowB + h * 16;  // row-block fragment (ds_read_b128), k-step 0
+  // lane parts of the fragment addresses.  Row fragment (ds_read_b128) of k-step s: row 32 rg + li, chunk 2 s + h.
+  int fo[NKO];
+#pragma unroll
+  for (int s = 0; s < NKO; ++s) fo[s] = sw_off(rg * 32 + li, (2 * s + h) * 16);
+  // Transposing read of k-step s, half j: lane 4q + pp of 16-lane group g supplies row 16 s + 8 (g >> 1) + 4 j + q,
+  // bytes 64 slab + 32 (g & 1) + 8 pp .. +7; bits 4.. of the row do not enter the swizzle, so the k-step is an offset
   const int g = lane >> 4, i16 = lane & 15;
-  const int tro = ((8 * (g >> 1) + (i16 >> 2)) * kRowB) + (16 * (g & 1) + 4 * (i16 & 3)) * 2;  // transposing read, k-step 0
+  int troY[2], troP[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = 8 * (g >> 1) + 4 * j + (i16 >> 2), b = 32 * (g & 1) + 8 * (i16 & 3);
+    troY[j] = sw_off(r, 64 * so + b);
+    troP[j] = sw_off(r, 64 * sc + b);
+  }
 
   f32x16 dw_hi, dw_lo;  // running dW block: the hi x hi products and the five correction products apart
 #pragma unroll
@@ -412,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void linear_x3_bwd_kernel(
         a.x = z.x > 0.f ? z.x : mx; a.y = z.y > 0.f ? z.y : my; a.z = z.z > 0.f ? z.z : mz; a.w = z.w > 0.f ? z.w : mw;
       }
       const Pk3 y01 = split2(y.x, y.y), y23 = split2(y.z, y.w), a01 = split2(a.x, a.y), a23 = split2(a.z, a.w);
-      const int off = (wave * 16 + it * 4 + rsub) * kRowB + csub * 8;
+      const int off = sw_off(wave * 16 + it * 4 + rsub, csub * 8);
       *reinterpret_cast<u32x2*>(Yimg + off) = u32x2{y01.h, y23.h};
       *reinterpret_cast<u32x2*>(Yimg + off + kImg64B) = u32x2{y01.m, y23.m};
       *reinterpret_cast<u32x2*>(Yimg + off + 2 * kImg64B) = u32x2{y01.l, y23.l};
@@ -431,22 +454,21 @@ __global__ __launch_bounds__(256, 2) void linear_x3_bwd_kernel(
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const unsigned char* ab = Yimg + rg * 32 * kRowB + fo;
 #pragma unroll
       for (int s = 0; s < NKO; ++s) {
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ab + s * 32);
-        const bf16x8 am = *reinterpret_cast<const bf16x8*>(ab + s * 32 + kImg64B);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(ab + s * 32 + 2 * kImg64B);
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Yimg + fo[s]);
+        const bf16x8 am = *reinterpret_cast<const bf16x8*>(Yimg + fo[s] + kImg64B);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(Yimg + fo[s] + 2 * kImg64B);
         acc = mfma_lo(acc, ah, am, al, wtf[s][0], wtf[s][1], wtf[s][2]);
       }
 #pragma unroll
       for (int s = 0; s < NKO; ++s) {
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ab + s * 32);
-        const bf16x8 am = *reinterpret_cast<const bf16x8*>(ab + s * 32 + kImg64B);
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Yimg + fo[s]);
+        const bf16x8 am = *reinterpret_cast<const bf16x8*>(Yimg + fo[s] + kImg64B);
         acc = mfma_mid(acc, ah, am, wtf[s][0], wtf[s][1]);
       }
 #pragma unroll
-      for (int s = 0; s < NKO; ++s) acc = mfma_hi(acc, *reinterpret_cast<const bf16x8*>(ab + s * 32), wtf[s][0]);
+      for (int s = 0; s < NKO; ++s) acc = mfma_hi(acc, *reinterpret_cast<const bf16x8*>(Yimg + fo[s]), wtf[s][0]);
 #pragma unroll
       for (int r = 0; r < 16; ++r) Stg[(rg * 32 + d_row(r, lane)) * 64 + sg * 32 + li] = acc[r];
     }
@@ -454,13 +476,14 @@ __global__ __launch_bounds__(256, 2) void linear_x3_bwd_kernel(
     X3_STAMP(4);
     // ---- dW block (so, sc) over the 64 rows of the tile: both operands by transposing reads ----
     if (has_tile) {  // wave-uniform
-      const unsigned char* ya = Yimg + tro + so * 64;
-      const unsigned char* pa = Pimg + tro + sc * 64;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const int ko = s * 16 * kRowB;
-        const bf16x8 ah = tr_frag(ya + ko), am = tr_frag(ya + ko + kImg64B), al = tr_frag(ya + ko + 2 * kImg64B);
-        const bf16x8 bh = tr_frag(pa + ko), bm = tr_frag(pa + ko + kImg64B), bl = tr_frag(pa + ko + 2 * kImg64B);
+        const unsigned char* ya = Yimg + s * 16 * kBRowB;
+        const unsigned char* pa = Pimg + s * 16 * kBRowB;
+        const bf16x8 ah = tr_frag(ya, troY[0], troY[1]), am = tr_frag(ya + kImg64B, troY[0], troY[1]),
+                     al = tr_frag(ya + 2 * kImg64B, troY[0], troY[1]);
+        const bf16x8 bh = tr_frag(pa, troP[0], troP[1]), bm = tr_frag(pa + kImg64B, troP[0], troP[1]),
+                     bl = tr_frag(pa + 2 * kImg64B, troP[0], troP[1]);
         dw_lo = mfma_lo(dw_lo, ah, am, al, bh, bm, bl);
         dw_lo = mfma_mid(dw_lo, ah, am, bh, bm);
         dw_hi = mfma_hi(dw_hi, ah, bh);
