@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "x3.h"
 
 namespace {
 
@@ -46,26 +47,9 @@ __device__ float4 gl_zero4[1];
 
 __device__ __forceinline__ int d_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-// ---- exact 3-way bf16 operand split (x3.h; the same arithmetic as linear_x3.hip) ----
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
-}
-struct Pk3 {
-  unsigned h, m, l;
-};
-__device__ __forceinline__ Pk3 split2(float a, float b) {
-  Pk3 p;
-  p.h = pk_bf16(a, b);
-  float ra = a - __uint_as_float(p.h << 16), rb = b - __uint_as_float(p.h & 0xffff0000u);
-  p.m = pk_bf16(ra, rb);
-  ra -= __uint_as_float(p.m << 16);
-  rb -= __uint_as_float(p.m & 0xffff0000u);
-  p.l = pk_bf16(ra, rb);
-  return p;
-}
+using gcl::x3::bf16x8;  // exact 3-way bf16 operand split: x3.h
+using gcl::x3::Pk3;
+using gcl::x3::split2;
 constexpr int kWRowB = 144;  // bytes per row of a weight piece image: 64 bf16 + 16 (conflict-free ds_read_b128 fragments)
 
 template <int ACT>

@@ -1307,7 +1307,20 @@ int launch_gemm(const float* X, int64_t ldx, int akind, const float* slope, cons
   if (rows == 0) return GCL_OK;
   GCL_CHECK_ARG((K % 4 == 0) && (ldx % 4 == 0) && gcl::aligned16(X), "dense: wide shapes need K %% 4 == 0 and 16-B aligned rows (K=%d ldx=%lld)", K, (long long)ldx);
   GCL_CHECK_ARG((ldw % 4 == 0) && gcl::aligned16(W) && (!trans || N % 4 == 0), "dense: wide shapes need a 16-B aligned weight block (ldw=%lld N=%d)", (long long)ldw, N);
-  const GtGeom g = gt_geom(rows, N);
+  GtGeom g = gt_geom(rows, N);
+  // split-operand bf16 variant (gemm_tile_x3_kernel): non-transposed weights, 128-row tiles
+  static const int x3_tile = [] { const char* e = getenv("GCL_X3"); const char* f = getenv("GCL_X3_TILE");
+                                  return ((e && atoi(e) == 0) || (f && atoi(f) == 0)) ? 0 : 1; }();
+  if (x3_tile && !trans && g.mi == 2) {
+    auto kern = gemm_tile_x3_kernel<EPI>;
+    { static bool lds_set = false;
+      if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } }
+    hipLaunchKernelGGL(kern, dim3(g.grid), dim3(256), gtx3_lds(), st, X, ldx, akind, slope, W, ldw, bias, Y, ldy, rows, K, N,
+                       Z, ldz, add, ldadd, slope_part, g.nt, g.total, g.per_xcd);
+    GCL_CHECK_LAUNCH();
+    if (nparts) *nparts = (int)g.grid;
+    return GCL_OK;
+  }
 #define GCL_GT(T_, MI_)                                                                                           \
   do {                                                                                                            \
     auto kern = gemm_tile_kernel<EPI, T_, MI_>;                                                                   \

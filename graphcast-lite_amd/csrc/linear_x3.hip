@@ -12,8 +12,6 @@
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -31,48 +29,7 @@ __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned off, 
 __device__ float4 x3_zero4[1];
 __device__ __forceinline__ int d_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-// ---- the split -------------------------------------------------------------------------------
-// two fp32 -> two packed bf16, round to nearest even (low half = a)
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
-}
-struct Pk3 {
-  unsigned h, m, l;  // packed (a, b) pieces: a + b exactly = hi + mid + lo each
-};
-__device__ __forceinline__ Pk3 split2(float a, float b) {
-  Pk3 p;
-  p.h = pk_bf16(a, b);
-  float ra = a - __uint_as_float(p.h << 16), rb = b - __uint_as_float(p.h & 0xffff0000u);  // exact: <= 16 bits left
-  p.m = pk_bf16(ra, rb);
-  ra -= __uint_as_float(p.m << 16);  // exact: <= 8 bits left, so the last rounding is exact too
-  rb -= __uint_as_float(p.m & 0xffff0000u);
-  p.l = pk_bf16(ra, rb);
-  return p;
-}
-
-// acc += (ah + am + al) x (bh + bm + bl) without the three smallest piece products, in three passes over the
-// k-steps, smallest terms first: the 2^-16-level products, then the 2^-8-level ones, and the hi x hi products
-// last.  The accumulator therefore stays small while the corrections are summed (their rounding errors are
-// relative to the CORRECTION, not to the result) and the full-size terms land on top of an already exact-to-
-// fp32 correction: the same error structure as a compensated sum.  (Adding the corrections to a full-size
-// accumulator - or riding the bias in its initial value - costs up to ~10 ulp: the matrix pipe does not
-// round each of its internal additions to nearest.)
-__device__ __forceinline__ f32x16 mfma_lo(f32x16 acc, bf16x8 ah, bf16x8 am, bf16x8 al, bf16x8 bh, bf16x8 bm, bf16x8 bl) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
-  return acc;
-}
-__device__ __forceinline__ f32x16 mfma_mid(f32x16 acc, bf16x8 ah, bf16x8 am, bf16x8 bh, bf16x8 bm) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
-  return acc;
-}
-__device__ __forceinline__ f32x16 mfma_hi(f32x16 acc, bf16x8 ah, bf16x8 bh) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-}
+using namespace gcl::x3;  // pk_bf16, Pk3, split2, mfma_lo / _mid / _hi, bf16x8 (x3.h)
 
 // LDS image of a [32 rows][64 k] bf16 piece: 144-byte rows (128 + 16): the 16 lanes one ds_read_b128 cycle
 // serves ({0-3,12-15,20-27} ...) then sit on 16 distinct 4-bank groups.  Three piece images back to back.

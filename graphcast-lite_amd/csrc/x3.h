@@ -29,3 +29,54 @@ int x3_linear_bwd(const float* dy, int64_t lddy, const float* W, const float* x,
                   float* part_cs, double* part_slope, hipStream_t st);
 
 }  // namespace gcl
+
+#ifdef __HIPCC__
+// ---- device side: the split and the MFMA passes shared by linear_x3.hip, gcn_layer.hip and gemm_tile.h ----
+namespace gcl {
+namespace x3 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// two fp32 -> two packed bf16, round to nearest even (low half = a): v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+struct Pk3 {
+  unsigned h, m, l;  // packed (a, b) pieces: a = hi + mid + lo exactly, likewise b
+};
+__device__ __forceinline__ Pk3 split2(float a, float b) {
+  Pk3 p;
+  p.h = pk_bf16(a, b);
+  float ra = a - __uint_as_float(p.h << 16), rb = b - __uint_as_float(p.h & 0xffff0000u);  // exact: <= 16 bits left
+  p.m = pk_bf16(ra, rb);
+  ra -= __uint_as_float(p.m << 16);  // exact: <= 8 bits left, so the last rounding is exact too
+  rb -= __uint_as_float(p.m & 0xffff0000u);
+  p.l = pk_bf16(ra, rb);
+  return p;
+}
+
+// acc += (ah + am + al) x (bh + bm + bl) without the three smallest piece products, as three groups that callers
+// run smallest first over all their k-steps (or keep in separate accumulators): the 2^-16-level products, the
+// 2^-8-level ones, hi x hi.  Adding corrections to a full-size accumulator costs ~10 ulp: the matrix pipe does not
+// round each of its internal additions to nearest.
+__device__ __forceinline__ f32x16 mfma_lo(f32x16 acc, bf16x8 ah, bf16x8 am, bf16x8 al, bf16x8 bh, bf16x8 bm, bf16x8 bl) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ f32x16 mfma_mid(f32x16 acc, bf16x8 ah, bf16x8 am, bf16x8 bh, bf16x8 bm) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ f32x16 mfma_hi(f32x16 acc, bf16x8 ah, bf16x8 bh) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+
+}  // namespace x3
+}  // namespace gcl
+#endif
