@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4 copy is 6290
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's headline 5 PF includes 2:1 sparsity)
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (MI355X_MICROARCH.md): 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
 
 
@@ -414,9 +415,20 @@ def main():
         D, E = cfg.pipeline.processor.gcn.output_dim, int(model.processing_graph.shape[1])
         flops = 2.0 * B * E * D * D
         achieved = flops / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_tile_kernel (InteractionNet edge MLP, [B*E, D] x [D, D], forward)",
-                "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                "traffic": None, "flops_per_launch": flops, "avg_launch_us": ms * 1e3, "launches_timed": cnt}
+        x3 = os.environ.get("GCL_X3", "1") != "0" and os.environ.get("GCL_X3_TILE", "1") != "0"
+        if x3:
+            # the contraction runs on the bf16 matrix pipe: every fp32 product costs SIX bf16 MFMA products (csrc/x3.h), so
+            # the executed matrix flops are 6x the algorithmic ones and the peak is the dense bf16 one
+            roof = {"bound": "mfma", "kernel": "gemm_tile_x3_kernel (InteractionNet edge MLP, [B*E, D] x [D, D], forward; "
+                                               "fp32 operands split exactly into 3 bf16 pieces, 6 piece products each)",
+                    "achieved": 6.0 * achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": 6.0 * achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "flops_per_launch": 6.0 * flops,
+                    "fp32_equivalent_tflops": achieved, "fp32_operand_mfma_peak": MFMA_F32_PEAK_TFLOPS,
+                    "avg_launch_us": ms * 1e3, "launches_timed": cnt}
+        else:
+            roof = {"bound": "mfma", "kernel": "gemm_tile_kernel (InteractionNet edge MLP, [B*E, D] x [D, D], forward)",
+                    "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                    "traffic": None, "flops_per_launch": flops, "avg_launch_us": ms * 1e3, "launches_timed": cnt}
 
     if rank == 0:
         out = {
