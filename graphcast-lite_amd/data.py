@@ -82,18 +82,21 @@ class TimeseriesChunkDataset:
     def grid_nodes(self) -> int:
         return self.n_nodes if self.flat_grid else self.n_lon * self.n_lat
 
-    def batch(self, indices: Sequence[int]) -> Tuple[torch.Tensor, torch.Tensor]:
+    def batch(self, indices: Sequence[int], out=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """A whole batch of windows in one launch per chunk.  out = (X, Y): fill these buffers in place (e.g.
+        `TrainStep.input_buffers()`, so that the captured step needs no copy of the batch)."""
         pairs = [self._sample_indices[int(i)] for i in indices]
         B, G = len(pairs), self.grid_nodes
         by_chunk = {}
         for pos, (ci, t) in enumerate(pairs):
             by_chunk.setdefault(ci, []).append((pos, t))
-        X = Y = None
+        X, Y = out if out is not None else (None, None)
         for ci, items in by_chunk.items():
             t0 = torch.tensor([t for _, t in items], dtype=torch.int64).to(self.device)
-            x, y = hip.window_pack(self.chunks[ci], t0, self.mean, self.std, self.n_feat, self.obs_window, self.pred_steps)
             if len(by_chunk) == 1:
-                return x, y
+                return hip.window_pack(self.chunks[ci], t0, self.mean, self.std, self.n_feat, self.obs_window,
+                                       self.pred_steps, out=out)
+            x, y = hip.window_pack(self.chunks[ci], t0, self.mean, self.std, self.n_feat, self.obs_window, self.pred_steps)
             if X is None:
                 X = torch.empty(B, G, x.shape[-1], dtype=torch.float32, device=self.device)
                 Y = torch.empty(B, G, y.shape[-1], dtype=torch.float32, device=self.device)

@@ -710,9 +710,10 @@ def act_bwd(x, dy, act, slope=None, d_slope=None):
     return dx
 
 
-def window_pack(series, t0, mean, std, C: int, obs: int, pred: int):
+def window_pack(series, t0, mean, std, C: int, obs: int, pred: int, out=None):
     """series: fp16 [T, n_lon, n_lat, Ct] (or flat [T, N, Ct]) on the GPU; t0: int64 [B] window starts on
-    the GPU.  Returns X [B, G, obs*C] and Y [B, G, pred*C] (None when pred == 0)."""
+    the GPU.  Returns X [B, G, obs*C] and Y [B, G, pred*C] (None when pred == 0).  out = (X, Y): contiguous fp32
+    buffers of those shapes to fill in place (e.g. TrainStep.input_buffers())."""
     assert series.is_cuda and series.dtype == torch.float16 and series.is_contiguous()
     assert t0.is_cuda and t0.dtype == torch.int64 and t0.is_contiguous()
     if series.dim() == 3:
@@ -721,8 +722,13 @@ def window_pack(series, t0, mean, std, C: int, obs: int, pred: int):
     else:
         T, n_lon, n_lat, Ct = series.shape
     B, G = t0.numel(), n_lon * n_lat
-    X = torch.empty(B, G, obs * C, dtype=torch.float32, device=series.device)
-    Y = torch.empty(B, G, pred * C, dtype=torch.float32, device=series.device) if pred > 0 else None
+    if out is not None:
+        X, Y = out
+        assert X.is_contiguous() and X.shape == (B, G, obs * C) and X.dtype == torch.float32 and X.device == series.device
+        assert pred == 0 or (Y.is_contiguous() and Y.shape == (B, G, pred * C) and Y.dtype == torch.float32)
+    else:
+        X = torch.empty(B, G, obs * C, dtype=torch.float32, device=series.device)
+        Y = torch.empty(B, G, pred * C, dtype=torch.float32, device=series.device) if pred > 0 else None
     _check(lib().gcl_window_pack(series.data_ptr(), T, n_lon, n_lat, Ct, t0.data_ptr(), _p(mean), _p(std), C, obs, pred,
                                  _p(X), _p(Y), B, _stream()))
     return X, Y

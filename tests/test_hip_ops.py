@@ -651,6 +651,11 @@ def test_window_pack_matches_loader_bit_for_bit(hip, flat, tmp_path):
     t0 = torch.tensor([T - 2], dtype=torch.int64, device=DEV)
     Xo, Yo = hip.window_pack(ds.chunks[0], t0, ds.mean, ds.std, C, obs, pred)
     assert not torch.isnan(Xo).any() and torch.isnan(Yo).all()
+    # batch(out=...) fills caller-owned buffers in place (TrainStep.input_buffers())
+    Xa, Ya = ds.batch([3, 0, 4])
+    bufs = (torch.full_like(Xa, -7.0), torch.full_like(Ya, -7.0))
+    Xb, Yb = ds.batch([3, 0, 4], out=bufs)
+    assert Xb.data_ptr() == bufs[0].data_ptr() and torch.equal(Xb, Xa) and torch.equal(Yb, Ya)
 
 
 @pytest.mark.parametrize("levels,Fin,Fout,B,act", [([1, 2], 64, 64, 3, 1), ([3, 5], 64, 48, 9, 0), ([1, 2], 48, 33, 2, 2),
