@@ -15,6 +15,10 @@ namespace {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef GCL_X3_ST_AUX
+#define GCL_X3_ST_AUX 2  // cache-policy bits of the streamed-out stores: 2 = non-temporal (measured +1.1 % end to end: the outputs are
+                         // consumed by a LATER kernel, keeping them out of the producer XCD's L2 leaves it to the inputs); 0 = default
+#endif
 constexpr unsigned kOOB = 0x80000000u;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int64_t nbytes) {
   const int64_t cap = 0x7FFFFF00;
@@ -24,7 +28,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, in
 __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v) {
   u32x4 u = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z),
              __builtin_bit_cast(unsigned, v.w)};
-  __builtin_amdgcn_raw_buffer_store_b128(u, r, off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, off, 0, GCL_X3_ST_AUX);
 }
 __device__ float4 x3_zero4[1];
 __device__ __forceinline__ int d_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
