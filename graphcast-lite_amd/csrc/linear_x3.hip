@@ -31,6 +31,16 @@ __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned off, 
   __builtin_amdgcn_raw_buffer_store_b128(u, r, off, 0, GCL_X3_ST_AUX);
 }
 __device__ float4 x3_zero4[1];
+// rows that this kernel reads exactly once: non-temporal loads (measured +0.7 % end to end; -DGCL_X3_LD_PLAIN: plain)
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+#ifndef GCL_X3_LD_PLAIN
+  typedef float lv4f __attribute__((ext_vector_type(4)));
+  const lv4f v = __builtin_nontemporal_load(reinterpret_cast<const lv4f*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
 __device__ __forceinline__ int d_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 using namespace gcl::x3;  // pk_bf16, Pk3, split2, mfma_lo / _mid / _hi, bf16x8 (x3.h)
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void linear_x3_fwd_kernel(const float* __re
     for (int it = 0; it < 8; ++it) {
       const int64_t row = r0 + it * 4 + rsub;
       const float4* p = (cok && row < rows_ld) ? reinterpret_cast<const float4*>(X + row * ldx + csub * 4) : x3_zero4;
-      pre[it] = *p;
+      pre[it] = ld_stream(p);
     }
   };
   auto commit = [&]() {
@@ -344,8 +354,8 @@ __global__ __launch_bounds__(256, 2) void linear_x3_bwd_kernel(
     for (int it = 0; it < 4; ++it) {
       const int64_t row = r0 + it * 4 + rsub;
       const bool rok = row < rows;
-      pre_y[it] = *((yok && rok) ? reinterpret_cast<const float4*>(dY + row * lddy + csub * 4) : x3_zero4);
-      pre_p[it] = *((pok && rok) ? reinterpret_cast<const float4*>(P + row * ldp + csub * 4) : x3_zero4);
+      pre_y[it] = ld_stream((yok && rok) ? reinterpret_cast<const float4*>(dY + row * lddy + csub * 4) : x3_zero4);
+      pre_p[it] = ld_stream((pok && rok) ? reinterpret_cast<const float4*>(P + row * ldp + csub * 4) : x3_zero4);
     }
   };
 
