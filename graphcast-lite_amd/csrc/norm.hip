@@ -15,7 +15,15 @@ __device__ __forceinline__ float group_sum(float v) {
 
 __device__ __forceinline__ void load4(const float* p, int c0, int F, bool vec, float& a, float& b, float& c, float& d) {
   if (vec) {
+    // the rows of these kernels are read exactly once: non-temporal loads keep them from displacing what the NEXT
+    // kernel gathers out of the L2 (the aggregation that follows the LayerNorm backward reads 2 % faster; end to end
+    // unchanged).  -DGCL_NORM_LD_PLAIN: plain loads.
+#ifndef GCL_NORM_LD_PLAIN
+    typedef float lv4f __attribute__((ext_vector_type(4)));
+    const lv4f v = __builtin_nontemporal_load(reinterpret_cast<const lv4f*>(p));
+#else
     const float4 v = *reinterpret_cast<const float4*>(p);
+#endif
     a = v.x; b = v.y; c = v.z; d = v.w;
   } else {
     a = (c0 < F) ? p[0] : 0.f;
