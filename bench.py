@@ -205,7 +205,10 @@ def init_dist(args):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("GCL_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        backend = os.environ.get("GCL_DIST_BACKEND", "nccl")
+        if backend == "nccl" and local < torch.cuda.device_count():
+            torch.cuda.set_device(local)  # RCCL binds its communicator to the current device: set it BEFORE the group exists
+        dist.init_process_group(backend, rank=rank, world_size=world)
         world = dist.get_world_size()  # what the process group really has
     return world, rank, local
 
