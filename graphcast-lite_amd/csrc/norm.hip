@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   }
 }
 
-constexpr int kNormBlocks = 512;
+constexpr int kNormBlocks = 1024;  // 4 blocks per CU (measured: 512 -> 1024 +1.8 % end to end, 2048 the same, 4096 less)
 
 inline int lpr_for(int F) {
   const int lanes = (F + 3) / 4;
