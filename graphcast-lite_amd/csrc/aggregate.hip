@@ -254,6 +254,169 @@ __global__ __launch_bounds__(256) void agg_heavy_kernel(const int32_t* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Source-tile ("halo") aggregation.  agg_kernel gathers every edge's source row through the L1/TA path: B*E' rows
+// per launch, ~3.4x the algorithmic bytes on the mesh graph, and that path (not HBM) bounds it.  Here a block owns
+// a tile of T consecutive rows: it stages the tile's DISTINCT source rows once (LDS-DMA row gather, the list is
+// precomputed per graph: gcl_halo) and forms every sum from LDS, so the vector-memory path carries each source
+// once per tile instead of once per edge.  With tiles that share sources well (mesh nodes numbered by recursive
+// coordinate bisection: 1.7 source rows per destination row at T = 64 instead of 7.4 edge reads) HBM is the bound.
+//
+// Block = 4 waves.  {tile count} -> {list entries of this wave's DMA pieces, edge records of this wave's rows}
+// -> LDS-DMA of the source rows -> barrier -> sums: a row is owned by LPR lanes (4 channels each), its first 16
+// edge records {image position, weight} sit one per lane and are broadcast with DPP row_newbcast (no LDS traffic),
+// the source values come from ds_read_b128 (conflict-free for any row set: 16 lanes x 16 B span all 64 banks).
+// Slots 0..7 are read unconditionally (padding points at a zero row with weight 0), slots 8..15 when some row of
+// the wave-instruction has that many edges, rows with more than 16 edges finish from the CSR arrays.
+// Arithmetic is that of agg_kernel<.., EW = 8>, bit for bit: product and sum rounded separately for the first
+// eight edges of a row (PyG's multiply, then scatter_add), fused multiply-add for the rest, in CSR order.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void* gcl_gptr_t;
+typedef __attribute__((address_space(3))) void* gcl_lptr_t;
+
+template <int K>
+__device__ __forceinline__ int row_bcast(int v) {  // lane K of every 16-lane row, to all lanes of the row
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xf, 0xf, false);
+}
+
+// product and sum rounded separately (PyG: message = w * x_j, then scatter_add); `x * y` alone may be contracted
+__device__ __forceinline__ float mul_then_add(float wk, float v, float a) {
+#pragma clang fp contract(off)
+  const float t = wk * v;
+  return a + t;
+}
+
+template <int LPR, int T, int MAXPW>
+__global__ __launch_bounds__(256) void agg_halo_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ cnt,
+                                                       const int2* __restrict__ rec, const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ opos, const float* __restrict__ w,
+                                                       int32_t smax, const float* __restrict__ H, int64_t ldh,
+                                                       int64_t bsh, const float* __restrict__ bias,
+                                                       float* __restrict__ Y, int64_t ldy, int64_t bsy, int32_t n,
+                                                       int32_t B, int32_t F, int32_t ntiles, int32_t xcd_map,
+                                                       int32_t nt_store) {
+  extern __shared__ float4 img[];  // [(smax + 1) * LPR]: staged source rows, then the zero row
+  constexpr int RPW = 64 / LPR;    // rows per wave-instruction
+  constexpr int NIT = T / 4 / RPW; // wave-instructions of rows per wave
+  const int bid = blockIdx.x;
+  int b, tile;
+  if (xcd_map) {
+    const int xcd = bid & (gcl::kNumXCD - 1);
+    const int slot = bid >> 3;
+    b = xcd + gcl::kNumXCD * (slot / ntiles);
+    tile = slot % ntiles;
+  } else {
+    b = bid / ntiles;
+    tile = bid % ntiles;
+  }
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform (scalar branches below)
+  const int sub = lane / LPR;
+  const int l = lane % LPR;
+  const int c0 = l * 4;
+  const bool cactive = c0 < F;
+  const int cc = cactive ? c0 : 0;  // inactive channel lanes stage channel 0 again (never stored)
+  const float* __restrict__ Hb = H + (int64_t)b * bsh;
+  float* __restrict__ Yb = Y + (int64_t)b * bsy;
+
+  if (threadIdx.x < LPR) img[smax * LPR + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int npieces = cnt[tile] / RPW;
+  const int32_t* __restrict__ tl = list + (int64_t)tile * smax;
+  // list entries of this wave's pieces (piece p = entries [p*RPW, (p+1)*RPW), handled by wave p % 4)
+  int jj[MAXPW];
+#pragma unroll
+  for (int q = 0; q < MAXPW; ++q) {
+    const int p = wave + 4 * q;
+    jj[q] = tl[min(p * RPW + sub, smax - 1)];  // unconditional (every entry of a tile's list is a valid row)
+  }
+  // edge records of this wave's rows
+  const int row0 = tile * T + wave * (T / 4) + sub;
+  int2 rc[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = row0 + it * RPW;
+    rc[it] = rec[(int64_t)(row < n ? row : n - 1) * gcl::kHaloRec + (l & (gcl::kHaloRec - 1))];
+  }
+  // Every source address is formed BEFORE the first DMA: hipcc answers any use of a plain load's result while an
+  // LDS-DMA is in flight with s_waitcnt vmcnt(0), which would land the pieces one at a time.
+  const float* srcs[MAXPW];
+#pragma unroll
+  for (int q = 0; q < MAXPW; ++q) {
+    srcs[q] = Hb + (int64_t)jj[q] * ldh + cc;
+    asm volatile("" : "+v"(srcs[q]));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < MAXPW; ++q) {
+    const int p = wave + 4 * q;
+    if (p < npieces) __builtin_amdgcn_global_load_lds((gcl_gptr_t)srcs[q], (gcl_lptr_t)(img + p * 64), 16, 0, 0);
+  }
+  float bz0 = 0.f, bz1 = 0.f, bz2 = 0.f, bz3 = 0.f;
+  if (bias && cactive) {
+    const float4 bv = *reinterpret_cast<const float4*>(bias + c0);  // F % 4 == 0 on this path
+    bz0 = bv.x; bz1 = bv.y; bz2 = bv.z; bz3 = bv.w;
+  }
+  __syncthreads();  // waits for the wave's DMA (vmcnt(0)) and for everyone else's
+
+  const float4* __restrict__ mine = img + l;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = row0 + it * RPW;
+    const int rx = rc[it].x, rw = rc[it].y;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#define GCL_HALO_MULADD(K)                                   \
+  {                                                          \
+    const int pos = row_bcast<K>(rx);                        \
+    const float wk = __int_as_float(row_bcast<K>(rw));       \
+    const float4 v = mine[pos * LPR];                        \
+    a0 = mul_then_add(wk, v.x, a0);                  \
+    a1 = mul_then_add(wk, v.y, a1);                  \
+    a2 = mul_then_add(wk, v.z, a2);                  \
+    a3 = mul_then_add(wk, v.w, a3);                  \
+  }
+#define GCL_HALO_FMA(K)                                      \
+  {                                                          \
+    const int pos = row_bcast<K>(rx) & gcl::kHaloPosMask;    \
+    const float wk = __int_as_float(row_bcast<K>(rw));       \
+    const float4 v = mine[pos * LPR];                        \
+    a0 = __fmaf_rn(wk, v.x, a0);                             \
+    a1 = __fmaf_rn(wk, v.y, a1);                             \
+    a2 = __fmaf_rn(wk, v.z, a2);                             \
+    a3 = __fmaf_rn(wk, v.w, a3);                             \
+  }
+    GCL_HALO_MULADD(0) GCL_HALO_MULADD(1) GCL_HALO_MULADD(2) GCL_HALO_MULADD(3)
+    GCL_HALO_MULADD(4) GCL_HALO_MULADD(5) GCL_HALO_MULADD(6) GCL_HALO_MULADD(7)
+    const int last = row_bcast<15>(rx);  // slot 15 carries the row flags
+    if (__any(row_bcast<8>(rx) != smax)) {  // wave-uniform: some row here has more than 8 edges
+      GCL_HALO_FMA(8) GCL_HALO_FMA(9) GCL_HALO_FMA(10) GCL_HALO_FMA(11)
+      GCL_HALO_FMA(12) GCL_HALO_FMA(13) GCL_HALO_FMA(14) GCL_HALO_FMA(15)
+      if (__any((last & gcl::kHaloMore) != 0)) {  // more than 16 edges: the rest from the CSR arrays
+        const int rcl = row < n ? row : n - 1;
+        const int end = (last & gcl::kHaloMore) ? rowptr[rcl + 1] : 0;
+        for (int e = rowptr[rcl] + gcl::kHaloRec; e < end; ++e) {
+          const float wk = w[e];
+          const float4 v = mine[opos[e] * LPR];
+          a0 = __fmaf_rn(wk, v.x, a0);
+          a1 = __fmaf_rn(wk, v.y, a1);
+          a2 = __fmaf_rn(wk, v.z, a2);
+          a3 = __fmaf_rn(wk, v.w, a3);
+        }
+      }
+    }
+#undef GCL_HALO_MULADD
+#undef GCL_HALO_FMA
+    if (row < n && cactive && !(last & gcl::kHaloSkip)) {
+      a0 += bz0; a1 += bz1; a2 += bz2; a3 += bz3;
+      float* __restrict__ yp = Yb + (int64_t)row * ldy + c0;
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      v4f v = {a0, a1, a2, a3};
+      if (nt_store) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(yp));
+      else *reinterpret_cast<v4f*>(yp) = v;
+    }
+  }
+}
+
 int agg_env(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
@@ -263,7 +426,67 @@ struct AggArgs {
   const int32_t *rowptr, *col, *ecol, *heavy;
   const float *w, *ew;
   int ell_width, n_heavy;
+  const gcl_halo* halo;  // [2]: T = 64, T = 32 (T == 0: not built)
 };
+
+// Source-tile path: returns GCL_OK after launching, or -1 when this call is not eligible (agg_kernel runs instead).
+template <int LPR>
+int launch_agg_halo(const AggArgs& ga, const float* h, int64_t ldh, int64_t bsh, const float* bias, float* y,
+                    int64_t ldy, int64_t bsy, int32_t n, int32_t B, int32_t F, hipStream_t st) {
+  const int enabled = agg_env("GCL_AGG_HALO", 1);  // read per call: the parity tests switch it to compare the two kernels
+  static const int force_t = agg_env("GCL_AGG_HALO_T", 0);
+  static const int nt = agg_env("GCL_AGG_NT", 1);
+  if (!enabled || ga.ell_width != 8) return -1;  // the arithmetic below is that of agg_kernel<.., EW = 8>
+  constexpr int RPW = 64 / LPR;
+  const gcl_halo* hl = nullptr;
+  for (int t = 0; t < 2; ++t) {
+    const gcl_halo& c = ga.halo[t];
+    if (c.T == 0 || (force_t && c.T != force_t)) continue;
+    const int64_t lds = (int64_t)(c.smax + 1) * LPR * 16;
+    if (lds > (c.T == 64 ? 40 : 53) * 1024 || gcl::cdiv(c.smax / RPW, 4) > 32) continue;
+    hl = &c;
+    break;
+  }
+  if (!hl) return -1;
+  const int64_t lds = (int64_t)(hl->smax + 1) * LPR * 16;
+  const int maxpw = (int)gcl::cdiv(hl->smax / RPW, 4);
+  const int xcd_map = B >= gcl::kNumXCD ? 1 : 0;
+  const int64_t nb = xcd_map ? (int64_t)gcl::kNumXCD * gcl::cdiv(B, gcl::kNumXCD) * hl->ntiles : (int64_t)B * hl->ntiles;
+  GCL_CHECK_ARG(nb < (int64_t)INT32_MAX, "aggregate: grid too large");
+  dim3 grid((unsigned)nb), block(256);
+#define GCL_HALO_L(T_, MP_)                                                                                        \
+  hipLaunchKernelGGL((agg_halo_kernel<LPR, T_, MP_>), grid, block, (size_t)lds, st, hl->list, hl->cnt,               \
+                     reinterpret_cast<const int2*>(hl->rec), ga.rowptr, hl->opos, ga.w, hl->smax, h, ldh, bsh, bias, \
+                     y, ldy, bsy, n, B, F, hl->ntiles, xcd_map, nt)
+#define GCL_HALO_T(T_)                   \
+  do {                                   \
+    if (maxpw <= 8) GCL_HALO_L(T_, 8);   \
+    else if (maxpw <= 16) GCL_HALO_L(T_, 16); \
+    else GCL_HALO_L(T_, 32);             \
+  } while (0)
+  if (hl->T == 64) GCL_HALO_T(64);
+  else GCL_HALO_T(32);
+#undef GCL_HALO_T
+#undef GCL_HALO_L
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+template <int LPR>
+int launch_agg_heavy(const AggArgs& ga, const float* h, int64_t ldh, int64_t bsh, const float* bias, float* y,
+                     int64_t ldy, int64_t bsy, int32_t B, int32_t F, bool vl, bool vs, hipStream_t st) {
+  dim3 hgrid((unsigned)ga.n_heavy, (unsigned)B), block(256);
+#define GCL_AGGH(VL_, VS_)                                                                                       \
+  hipLaunchKernelGGL((agg_heavy_kernel<LPR, VL_, VS_>), hgrid, block, 0, st, ga.heavy, ga.rowptr, ga.col, ga.w, h, \
+                     ldh, bsh, bias, y, ldy, bsy, F)
+  if (vl && vs) GCL_AGGH(true, true);
+  else if (vl) GCL_AGGH(true, false);
+  else if (vs) GCL_AGGH(false, true);
+  else GCL_AGGH(false, false);
+#undef GCL_AGGH
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
 
 template <int LPR>
 int launch_agg(const AggArgs& ga, const float* h, int64_t ldh, int64_t bsh, const float* bias, float* y, int64_t ldy,
@@ -273,6 +496,15 @@ int launch_agg(const AggArgs& ga, const float* h, int64_t ldh, int64_t bsh, cons
   // vector loads need 16-B aligned rows and a padded tail (ldh >= roundup(F,4))
   const bool vl = (ldh % 4 == 0) && (bsh % 4 == 0) && gcl::aligned16(h) && ldh >= ((F + 3) / 4) * 4;
   const bool vs = (ldy % 4 == 0) && (bsy % 4 == 0) && gcl::aligned16(y) && (F % 4 == 0);
+  if constexpr (LPR >= 16) {
+    if (vl && vs && (!bias || gcl::aligned16(bias))) {
+      const int hr = launch_agg_halo<LPR>(ga, h, ldh, bsh, bias, y, ldy, bsy, n, B, F, st);
+      if (hr >= 0) {
+        if (hr != GCL_OK || ga.n_heavy == 0) return hr;
+        return launch_agg_heavy<LPR>(ga, h, ldh, bsh, bias, y, ldy, bsy, B, F, true, true, st);
+      }
+    }
+  }
   static const int iter_env = agg_env("GCL_AGG_ITER", 0);  // tuning overrides (0 = per-graph default)
   static const int ew_env = agg_env("GCL_AGG_EW", 0);
   static const int nt = agg_env("GCL_AGG_NT", 1);  // non-temporal output stores (measured: -7..-12 %)
@@ -313,18 +545,7 @@ int launch_agg(const AggArgs& ga, const float* h, int64_t ldh, int64_t bsh, cons
 #undef GCL_AGG3
 #undef GCL_AGG4
   GCL_CHECK_LAUNCH();
-  if (ga.n_heavy > 0) {
-    dim3 hgrid((unsigned)ga.n_heavy, (unsigned)B);
-#define GCL_AGGH(VL_, VS_)                                                                                       \
-  hipLaunchKernelGGL((agg_heavy_kernel<LPR, VL_, VS_>), hgrid, block, 0, st, ga.heavy, ga.rowptr, ga.col, ga.w, h, \
-                     ldh, bsh, bias, y, ldy, bsy, F)
-    if (vl && vs) GCL_AGGH(true, true);
-    else if (vl) GCL_AGGH(true, false);
-    else if (vs) GCL_AGGH(false, true);
-    else GCL_AGGH(false, false);
-#undef GCL_AGGH
-    GCL_CHECK_LAUNCH();
-  }
+  if (ga.n_heavy > 0) return launch_agg_heavy<LPR>(ga, h, ldh, bsh, bias, y, ldy, bsy, B, F, vl, vs, st);
   return GCL_OK;
 }
 
@@ -347,6 +568,7 @@ extern "C" int gcl_aggregate(const gcl_graph_t* g, int32_t transpose, const floa
   ga.ell_width = transpose ? g->tell_width : g->ell_width;
   ga.heavy = transpose ? g->theavy : g->heavy;
   ga.n_heavy = transpose ? g->n_theavy : g->n_heavy;
+  ga.halo = g->halo[transpose ? 1 : 0];
   GCL_CHECK_ARG(B <= 65535 || ga.n_heavy == 0, "aggregate: batch too large for the heavy-row launch");
   hipStream_t st = (hipStream_t)stream;
   const int lanes = (F + 3) / 4;

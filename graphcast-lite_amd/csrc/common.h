@@ -45,6 +45,10 @@ constexpr int kNumXCD = 8;    // MI355X: 8 XCDs, blocks are dealt round-robin ov
 constexpr int kNumCU = 256;
 constexpr int kEll = 8;      // stride of the ELL prefix arrays
 constexpr int kHeavy = 64;   // rows with more edges than this get a whole block
+constexpr int kHaloRec = 16;             // edge records per row held in registers (one per lane of a 16-lane row group)
+constexpr int kHaloMore = 1 << 30;       // flag in slot 15: the row has more than 16 edges (finish from the CSR arrays)
+constexpr int kHaloSkip = 1 << 29;       // flag in slot 15: heavy row, done by agg_heavy_kernel (do not store)
+constexpr int kHaloPosMask = 0xFFFF;
 
 __device__ __forceinline__ float prelu_f(float x, float a) { return x > 0.f ? x : a * x; }
 // Activation kinds of the dense kernels (GCL_ACT_* of gcl.h).  SiLU: x * sigmoid(x).
@@ -71,6 +75,19 @@ int launch_reduce_parts3(const float* part, int nparts, int64_t pstride, int pld
 
 }  // namespace gcl
 
+// Source-tile ("halo") layout of one CSR direction: the rows are cut into tiles of T consecutive rows and each
+// tile carries the list of DISTINCT source rows its edges read, so a block stages every source once in LDS
+// (LDS-DMA row gather) and forms the sums from LDS (csrc/aggregate.hip, agg_halo_kernel).  Built on the host
+// when the graph is created, and only when the tiling shares sources well enough to pay (graph.hip).
+struct gcl_halo {
+  int32_t T = 0, ntiles = 0;
+  int32_t smax = 0;          // stride of `list` = largest per-tile source count, rounded up to 8; image row `smax` is the zero row
+  int32_t* list = nullptr;   // [ntiles * smax] distinct source rows of a tile, ascending, padded by repeating the last one
+  int32_t* cnt = nullptr;    // [ntiles] entries to stage (multiple of 8)
+  int32_t* rec = nullptr;    // [n * 16 * 2] {image position | flags (slot 15), weight bits} of the first 16 edges of a row
+  int32_t* opos = nullptr;   // [E'] image position of every CSR slot (rows with more than 16 edges)
+};
+
 // Device-side graph arrays (owned by the handle).
 struct gcl_graph {
   int32_t n = 0;
@@ -89,6 +106,8 @@ struct gcl_graph {
   // rows with more than kHeavy edges: skipped by the row-group kernel, done by one block each
   int32_t *heavy = nullptr, *theavy = nullptr;
   int32_t n_heavy = 0, n_theavy = 0;
+  // source-tile layouts: [direction: 0 forward, 1 transpose][0: T = 64, 1: T = 32]; T == 0 when not built
+  gcl_halo halo[2][2];
   // host copy of the PyG-order edge list with loops (for export / prune)
   int64_t* h_edges = nullptr;  // [2, e]
 };

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -129,8 +130,85 @@ static int upload(T** dst, const T* src, size_t count) {
   return GCL_OK;
 }
 
+// Source tiles of one CSR direction (common.h, gcl_halo).  Returns false (nothing allocated) when the tiling
+// does not pay: fewer than 1.6 edge reads per staged source row, or a tile whose sources cannot fit in LDS.
+namespace {
+struct HaloHost {
+  int32_t T = 0, ntiles = 0, smax = 0;
+  std::vector<int32_t> list, cnt, rec, opos;
+};
+
+bool build_halo_host(const std::vector<int32_t>& rp, const std::vector<int32_t>& cl, const std::vector<float>& ww,
+                     int32_t n, int32_t T, HaloHost& h) {
+  const int32_t ntiles = (int32_t)gcl::cdiv(n, T);
+  if (ntiles < 2) return false;
+  std::vector<int32_t> mark(n, -1);
+  std::vector<std::vector<int32_t>> src(ntiles);
+  int64_t edges = 0, distinct = 0;
+  int32_t max_s = 0;
+  for (int32_t t = 0; t < ntiles; ++t) {
+    auto& sv = src[t];
+    for (int32_t i = t * T; i < n && i < (t + 1) * T; ++i) {
+      const int32_t d = rp[i + 1] - rp[i];
+      if (d > gcl::kHeavy) continue;  // heavy rows read global memory in their own kernel
+      edges += d;
+      for (int32_t e = rp[i]; e < rp[i + 1]; ++e)
+        if (mark[cl[e]] != t) {
+          mark[cl[e]] = t;
+          sv.push_back(cl[e]);
+        }
+    }
+    std::sort(sv.begin(), sv.end());
+    distinct += (int64_t)sv.size();
+    if ((int32_t)sv.size() > max_s) max_s = (int32_t)sv.size();
+  }
+  if (distinct == 0 || edges * 10 < distinct * 16) return false;
+  const int32_t smax = (max_s + 7) / 8 * 8;
+  if (smax > 1024 || smax >= gcl::kHaloPosMask) return false;
+  h.T = T;
+  h.ntiles = ntiles;
+  h.smax = smax;
+  h.list.assign((size_t)ntiles * smax, 0);
+  h.cnt.assign(ntiles, 0);
+  h.rec.assign((size_t)n * gcl::kHaloRec * 2, 0);
+  h.opos.assign(cl.size(), smax);
+  std::vector<int32_t> posof(n, 0);
+  for (int32_t t = 0; t < ntiles; ++t) {
+    const auto& sv = src[t];
+    const int32_t c = (int32_t)sv.size();
+    for (int32_t k = 0; k < smax; ++k) h.list[(size_t)t * smax + k] = c ? sv[k < c ? k : c - 1] : 0;
+    h.cnt[t] = (c + 7) / 8 * 8;
+    for (int32_t k = 0; k < c; ++k) posof[sv[k]] = k;
+    for (int32_t i = t * T; i < n && i < (t + 1) * T; ++i) {
+      const int32_t d = rp[i + 1] - rp[i];
+      const bool heavy = d > gcl::kHeavy;
+      int32_t* r = &h.rec[(size_t)i * gcl::kHaloRec * 2];
+      for (int k = 0; k < gcl::kHaloRec; ++k) {
+        const bool in = !heavy && k < d;
+        float wv = in ? ww[rp[i] + k] : 0.f;
+        int32_t wb;
+        memcpy(&wb, &wv, 4);
+        r[2 * k] = in ? posof[cl[rp[i] + k]] : smax;
+        r[2 * k + 1] = wb;
+      }
+      if (heavy) r[2 * (gcl::kHaloRec - 1)] |= gcl::kHaloSkip;
+      else if (d > gcl::kHaloRec) r[2 * (gcl::kHaloRec - 1)] |= gcl::kHaloMore;
+      if (!heavy)
+        for (int32_t e = rp[i]; e < rp[i + 1]; ++e) h.opos[e] = posof[cl[e]];
+    }
+  }
+  return true;
+}
+}  // namespace
+
 extern "C" void gcl_graph_destroy(gcl_graph_t* g) {
   if (!g) return;
+  for (int d = 0; d < 2; ++d)
+    for (int t = 0; t < 2; ++t) {
+      void* hp[] = {g->halo[d][t].list, g->halo[d][t].cnt, g->halo[d][t].rec, g->halo[d][t].opos};
+      for (void* p : hp)
+        if (p) (void)hipFree(p);
+    }
   void* ptrs[] = {g->rowptr, g->col, g->eperm, g->trowptr, g->tcol, g->tslot, g->w, g->tw,
                   g->ecol, g->tecol, g->ew, g->tew, g->heavy, g->theavy, g->teslot};
   for (void* p : ptrs)
@@ -246,6 +324,22 @@ extern "C" int gcl_graph_create(const int64_t* ei, int64_t E, int32_t n, int32_t
   g->n_theavy = (int32_t)thv.size();
   if (!rc) rc = upload(&g->heavy, hv.data(), hv.size());
   if (!rc) rc = upload(&g->theavy, thv.data(), thv.size());
+  // source-tile layouts (forward and transpose, T = 64 and 32)
+  for (int d = 0; d < 2 && !rc; ++d)
+    for (int t = 0; t < 2 && !rc; ++t) {
+      HaloHost hh;
+      const bool ok = d == 0 ? build_halo_host(rowptr, col, w, n, t == 0 ? 64 : 32, hh)
+                             : build_halo_host(trowptr, tcol, tw, n, t == 0 ? 64 : 32, hh);
+      if (!ok) continue;
+      gcl_halo& H = g->halo[d][t];
+      rc = upload(&H.list, hh.list.data(), hh.list.size());
+      if (!rc) rc = upload(&H.cnt, hh.cnt.data(), hh.cnt.size());
+      if (!rc) rc = upload(&H.rec, hh.rec.data(), hh.rec.size());
+      if (!rc) rc = upload(&H.opos, hh.opos.data(), (size_t)Ep);
+      H.T = hh.T;
+      H.ntiles = hh.ntiles;
+      H.smax = hh.smax;
+    }
   if (rc) {
     gcl_graph_destroy(g);
     return rc;
@@ -258,6 +352,16 @@ extern "C" int32_t gcl_graph_num_nodes(const gcl_graph_t* g) { return g ? g->n :
 extern "C" int64_t gcl_graph_num_edges(const gcl_graph_t* g) { return g ? g->e : 0; }
 extern "C" int32_t gcl_graph_max_in_degree(const gcl_graph_t* g) { return g ? g->max_in_deg : 0; }
 extern "C" const int32_t* gcl_graph_eperm_device(const gcl_graph_t* g) { return g ? g->eperm : nullptr; }
+extern "C" int gcl_graph_halo_info(const gcl_graph_t* g, int32_t transpose, int32_t T, int32_t* out4) {
+  GCL_CHECK_ARG(g && out4, "graph_halo_info: null argument");
+  GCL_CHECK_ARG(T == 64 || T == 32, "graph_halo_info: T must be 64 or 32");
+  const gcl_halo& h = g->halo[transpose ? 1 : 0][T == 64 ? 0 : 1];
+  out4[0] = h.T;
+  out4[1] = h.ntiles;
+  out4[2] = h.smax;
+  out4[3] = 0;
+  return GCL_OK;
+}
 extern "C" int gcl_graph_export_edges(const gcl_graph_t* g, int64_t* out) {
   GCL_CHECK_ARG(g && out, "graph_export_edges: null argument");
   memcpy(out, g->h_edges, sizeof(int64_t) * 2 * g->e);

@@ -32,6 +32,7 @@ _SIGNATURES = {
     "gcl_graph_max_in_degree": (_i32, [_vp]),
     "gcl_graph_export_edges": (C.c_int, [_vp, _vp]),
     "gcl_graph_eperm_device": (_vp, [_vp]),
+    "gcl_graph_halo_info": (C.c_int, [_vp, _i32, _i32, _vp]),
     "gcl_linear_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "gcl_linear_bwd_dx": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _sz, _vp]),
     "gcl_linear_bwd_dw": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
@@ -187,6 +188,12 @@ class Graph:
         out = torch.empty(2, self.e, dtype=torch.int64)
         _check(lib().gcl_graph_export_edges(self._h, out.data_ptr()))
         return out
+
+    def halo_info(self, transpose: bool = False, T: int = 64):
+        """(T, tiles, staged-source stride) of the source-tile layout, or None when it was not built."""
+        out = (C.c_int32 * 4)()
+        _check(lib().gcl_graph_halo_info(self._h, 1 if transpose else 0, T, out))
+        return (out[0], out[1], out[2]) if out[0] else None
 
     def edges_with_loops(self, device) -> torch.Tensor:
         key = str(torch.device(device))

@@ -298,3 +298,31 @@ def prune_mesh_to_region(
         ok = lvl[m.faces].all(axis=1)
         out.append(TriangularMesh(vertices=verts, faces=remap[m.faces[ok]].astype(np.int32)))
     return out
+
+
+def tile_order(points: np.ndarray, leaf: int = 64) -> np.ndarray:
+    """Node order in which every run of `leaf` consecutive nodes is a spatially compact patch: recursive
+    coordinate bisection along the widest axis, cut at multiples of `leaf` (ties broken by the original index,
+    so the result is deterministic).  Returns `order` with `order[new] = old`.
+
+    Not part of the reference: the mesh processor may number its rows freely because mesh nodes never leave the
+    model (inputs and outputs live on grid nodes, src/models.py:808-874).  With this order the neighbours of a
+    64-row tile of the mesh graph are 108 distinct rows instead of 211 in creation order, which is what lets the
+    aggregation stage a tile's sources once in LDS (csrc/aggregate.hip, agg_halo_kernel).  Each row keeps the
+    order of its in-edges, so every sum runs in the reference's order and results are unchanged bit for bit."""
+    pts = np.asarray(points, dtype=np.float64)
+    out = []
+    stack = [np.arange(len(pts))]
+    while stack:
+        ids = stack.pop()
+        if len(ids) <= leaf:
+            out.append(ids)
+            continue
+        p = pts[ids]
+        ax = int(np.argmax(p.max(0) - p.min(0)))
+        o = ids[np.argsort(p[:, ax], kind="stable")]
+        h = (len(o) // 2 + leaf - 1) // leaf * leaf
+        h = min(max(h, leaf), len(o) - 1)
+        stack.append(o[h:])  # popped after the low half: keeps the low half first
+        stack.append(o[:h])
+    return np.concatenate(out) if out else np.zeros(0, dtype=np.int64)

@@ -81,6 +81,12 @@ int32_t gcl_graph_max_in_degree(const gcl_graph_t* g);
 int gcl_graph_export_edges(const gcl_graph_t* g, int64_t* edge_index_out);
 /* Device pointer to eperm (int32 [E']), for callers that re-order per-slot data themselves. */
 const int32_t* gcl_graph_eperm_device(const gcl_graph_t* g);
+/* Source-tile ("halo") layout of one direction (transpose != 0: sender-sorted) for tile height T (64 or 32):
+ * out4 = {T (0 when that layout was not built), tiles, largest staged source count per tile (rounded up to 8),
+ * 0}.  gcl_graph_create builds it when a tile's edges share their sources well enough (>= 1.6 reads per staged
+ * row) - e.g. mesh nodes numbered tile by tile; gcl_aggregate then stages every source row of a tile once in
+ * LDS instead of gathering it once per edge (the propagate of src/models.py:419). */
+int gcl_graph_halo_info(const gcl_graph_t* g, int32_t transpose, int32_t T, int32_t* out4);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense per-node transform  y = act(x) W^T (+ bias)      [rows, Fin] x [Fout, Fin]^T
