@@ -18,6 +18,8 @@
 // never leave the XCD.  Placement is a speed choice only; results do not depend on it.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -276,7 +278,7 @@ typedef __attribute__((address_space(3))) void* gcl_lptr_t;
 
 template <int K>
 __device__ __forceinline__ int row_bcast(int v) {  // lane K of every 16-lane row, to all lanes of the row
-  return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xf, 0xf, false);
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xf, 0xf, true);  // bound_ctrl: no `old` operand to set up
 }
 
 // product and sum rounded separately (PyG: message = w * x_j, then scatter_add); `x * y` alone may be contracted
@@ -286,18 +288,33 @@ __device__ __forceinline__ float mul_then_add(float wk, float v, float a) {
   return a + t;
 }
 
-template <int LPR, int T, int MAXPW>
-__global__ __launch_bounds__(256) void agg_halo_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ cnt,
+#ifdef GCL_STAMPS
+__device__ unsigned long long agg_stamps[8 * 4096];  // diagnostic builds only (make STAMPS=1): per wave, cycles per phase
+#define GCL_AGG_STAMP(i)                                   \
+  {                                                        \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    st_acc[i] += t_ - st_last;                             \
+    st_last = t_;                                          \
+  }
+#else
+#define GCL_AGG_STAMP(i)
+#endif
+
+template <int LPR, int T, int MAXPW, int NW>
+__global__ __launch_bounds__(64 * NW) void agg_halo_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ cnt,
                                                        const int2* __restrict__ rec, const int32_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ opos, const float* __restrict__ w,
                                                        int32_t smax, const float* __restrict__ H, int64_t ldh,
                                                        int64_t bsh, const float* __restrict__ bias,
                                                        float* __restrict__ Y, int64_t ldy, int64_t bsy, int32_t n,
                                                        int32_t B, int32_t F, int32_t ntiles, int32_t xcd_map,
-                                                       int32_t nt_store) {
-  extern __shared__ float4 img[];  // [(smax + 1) * LPR]: staged source rows, then the zero row
+                                                       int32_t nt_store, int32_t skew) {
+  extern __shared__ float4 img[];  // [(smax + 1) * LPR]: the tile's own rows, its halo rows, then the zero row
   constexpr int RPW = 64 / LPR;    // rows per wave-instruction
-  constexpr int NIT = T / 4 / RPW; // wave-instructions of rows per wave
+  constexpr int NIT = T / NW / RPW; // wave-instructions of rows per wave (NW waves per block)
+#ifdef GCL_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
   const int bid = blockIdx.x;
   int b, tile;
   if (xcd_map) {
@@ -311,84 +328,108 @@ __global__ __launch_bounds__(256) void agg_halo_kernel(const int32_t* __restrict
   }
   if (b >= B) return;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform (scalar branches below)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform (scalar loads and branches below)
   const int sub = lane / LPR;
   const int l = lane % LPR;
   const int c0 = l * 4;
   const bool cactive = c0 < F;
   const int cc = cactive ? c0 : 0;  // inactive channel lanes stage channel 0 again (never stored)
-  const float* __restrict__ Hb = H + (int64_t)b * bsh;
+  // one sample's rows are addressed by 32-bit byte offsets from a scalar base (the launcher checks n * ldh * 4 < 2^31
+  // and ldh * 4 < 2^24): one v_mad_u32_u24 per row instead of a 64-bit multiply
+  const char* __restrict__ Hc = reinterpret_cast<const char*>(H + (int64_t)b * bsh);
+  const unsigned ldb = (unsigned)ldh * 4u, cb = (unsigned)cc * 4u;
   float* __restrict__ Yb = Y + (int64_t)b * bsy;
+  const int hstride = smax - T;
 
-  if (threadIdx.x < LPR) img[smax * LPR + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int npieces = cnt[tile] / RPW;
-  const int32_t* __restrict__ tl = list + (int64_t)tile * smax;
-  // list entries of this wave's pieces (piece p = entries [p*RPW, (p+1)*RPW), handled by wave p % 4)
+  // halo list entries of this wave's pieces: wave-uniform addresses -> scalar loads (lgkmcnt), so they neither wait
+  // for nor are waited for by the vector-memory counter the DMAs sit on.  Piece p = image rows [T + p*RPW, ..+RPW).
+  const int nhalo = cnt[tile] / RPW;
+  const int32_t* __restrict__ tl = list + (int64_t)tile * hstride;
   int jj[MAXPW];
 #pragma unroll
   for (int q = 0; q < MAXPW; ++q) {
-    const int p = wave + 4 * q;
-    jj[q] = tl[min(p * RPW + sub, smax - 1)];  // unconditional (every entry of a tile's list is a valid row)
+    const int e0 = min((wave + NW * q) * RPW, hstride - RPW);  // clamped: every entry of a tile's list is a valid row
+    int j = tl[e0];
+#pragma unroll
+    for (int r = 1; r < RPW; ++r) {
+      const int jr = tl[e0 + r];
+      j = sub == r ? jr : j;
+    }
+    jj[q] = j;
   }
-  // edge records of this wave's rows
-  const int row0 = tile * T + wave * (T / 4) + sub;
+  // (an LDS store issued while a DMA is in flight would make hipcc drain the DMAs first: zero row before them)
+  if (threadIdx.x < LPR) img[smax * LPR + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // own rows: no list, no dependency - in flight while the list arrives
+  const int row0 = tile * T + wave * (T / NW) + sub;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = row0 + it * RPW;
+    const char* src = Hc + (__umul24(row < n ? row : n - 1, ldb) + cb);
+    __builtin_amdgcn_global_load_lds((gcl_gptr_t)src, (gcl_lptr_t)(img + (wave * (T / NW) + it * RPW) * LPR), 16, 0, 0);
+  }
+  GCL_AGG_STAMP(0)  // entry .. own DMAs issued
+  if (skew) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // experiment: halo rows only after the own rows landed
+#pragma unroll
+  for (int q = 0; q < MAXPW; ++q) {
+    const int p = wave + NW * q;
+    if (p < nhalo) {
+      const char* src = Hc + (__umul24(jj[q], ldb) + cb);
+      __builtin_amdgcn_global_load_lds((gcl_gptr_t)src, (gcl_lptr_t)(img + (T + p * RPW) * LPR), 16, 0, 0);
+    }
+  }
+  // edge records of this wave's rows (used after the barrier)
   int2 rc[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int row = row0 + it * RPW;
     rc[it] = rec[(int64_t)(row < n ? row : n - 1) * gcl::kHaloRec + (l & (gcl::kHaloRec - 1))];
   }
-  // Every source address is formed BEFORE the first DMA: hipcc answers any use of a plain load's result while an
-  // LDS-DMA is in flight with s_waitcnt vmcnt(0), which would land the pieces one at a time.
-  const float* srcs[MAXPW];
-#pragma unroll
-  for (int q = 0; q < MAXPW; ++q) {
-    srcs[q] = Hb + (int64_t)jj[q] * ldh + cc;
-    asm volatile("" : "+v"(srcs[q]));
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int q = 0; q < MAXPW; ++q) {
-    const int p = wave + 4 * q;
-    if (p < npieces) __builtin_amdgcn_global_load_lds((gcl_gptr_t)srcs[q], (gcl_lptr_t)(img + p * 64), 16, 0, 0);
-  }
+  GCL_AGG_STAMP(1)  // list wait + halo DMAs + record loads issued
   float bz0 = 0.f, bz1 = 0.f, bz2 = 0.f, bz3 = 0.f;
   if (bias && cactive) {
     const float4 bv = *reinterpret_cast<const float4*>(bias + c0);  // F % 4 == 0 on this path
     bz0 = bv.x; bz1 = bv.y; bz2 = bv.z; bz3 = bv.w;
   }
   __syncthreads();  // waits for the wave's DMA (vmcnt(0)) and for everyone else's
+  GCL_AGG_STAMP(2)  // landed + barrier
 
-  const float4* __restrict__ mine = img + l;
+  // LDS byte address of this lane's 16 bytes of image row 0, as an integer: `row_bcast(offset) + lb` is then a plain
+  // two-operand add, which hipcc folds into ONE v_add_u32_dpp (broadcast + address) per edge
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) const v4f* lds4_t;
+  const unsigned lb = (unsigned)(size_t)((gcl_lptr_t)img) + (unsigned)l * 16u;
+  constexpr int SH = LPR == 16 ? 8 : LPR == 32 ? 9 : 10;  // log2 of the bytes of an image row
+  const int zrow = smax << SH;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int row = row0 + it * RPW;
     const int rx = rc[it].x, rw = rc[it].y;
+    const int rxb = (rx & gcl::kHaloPosMask) << SH;  // byte offset of the source's image row (slot 15: flags stripped)
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#define GCL_HALO_MULADD(K)                                   \
-  {                                                          \
-    const int pos = row_bcast<K>(rx);                        \
-    const float wk = __int_as_float(row_bcast<K>(rw));       \
-    const float4 v = mine[pos * LPR];                        \
-    a0 = mul_then_add(wk, v.x, a0);                  \
-    a1 = mul_then_add(wk, v.y, a1);                  \
-    a2 = mul_then_add(wk, v.z, a2);                  \
-    a3 = mul_then_add(wk, v.w, a3);                  \
+#define GCL_HALO_MULADD(K)                                          \
+  {                                                                 \
+    const unsigned ad = (unsigned)row_bcast<K>(rxb) + lb;           \
+    const float wk = __int_as_float(row_bcast<K>(rw));              \
+    const v4f v = *(lds4_t)ad;                                      \
+    a0 = mul_then_add(wk, v.x, a0);                                 \
+    a1 = mul_then_add(wk, v.y, a1);                                 \
+    a2 = mul_then_add(wk, v.z, a2);                                 \
+    a3 = mul_then_add(wk, v.w, a3);                                 \
   }
-#define GCL_HALO_FMA(K)                                      \
-  {                                                          \
-    const int pos = row_bcast<K>(rx) & gcl::kHaloPosMask;    \
-    const float wk = __int_as_float(row_bcast<K>(rw));       \
-    const float4 v = mine[pos * LPR];                        \
-    a0 = __fmaf_rn(wk, v.x, a0);                             \
-    a1 = __fmaf_rn(wk, v.y, a1);                             \
-    a2 = __fmaf_rn(wk, v.z, a2);                             \
-    a3 = __fmaf_rn(wk, v.w, a3);                             \
+#define GCL_HALO_FMA(K)                                             \
+  {                                                                 \
+    const unsigned ad = (unsigned)row_bcast<K>(rxb) + lb;           \
+    const float wk = __int_as_float(row_bcast<K>(rw));              \
+    const v4f v = *(lds4_t)ad;                                      \
+    a0 = __fmaf_rn(wk, v.x, a0);                                    \
+    a1 = __fmaf_rn(wk, v.y, a1);                                    \
+    a2 = __fmaf_rn(wk, v.z, a2);                                    \
+    a3 = __fmaf_rn(wk, v.w, a3);                                    \
   }
     GCL_HALO_MULADD(0) GCL_HALO_MULADD(1) GCL_HALO_MULADD(2) GCL_HALO_MULADD(3)
     GCL_HALO_MULADD(4) GCL_HALO_MULADD(5) GCL_HALO_MULADD(6) GCL_HALO_MULADD(7)
     const int last = row_bcast<15>(rx);  // slot 15 carries the row flags
-    if (__any(row_bcast<8>(rx) != smax)) {  // wave-uniform: some row here has more than 8 edges
+    if (__any(row_bcast<8>(rxb) != zrow)) {  // wave-uniform: some row here has more than 8 edges
       GCL_HALO_FMA(8) GCL_HALO_FMA(9) GCL_HALO_FMA(10) GCL_HALO_FMA(11)
       GCL_HALO_FMA(12) GCL_HALO_FMA(13) GCL_HALO_FMA(14) GCL_HALO_FMA(15)
       if (__any((last & gcl::kHaloMore) != 0)) {  // more than 16 edges: the rest from the CSR arrays
@@ -396,7 +437,7 @@ __global__ __launch_bounds__(256) void agg_halo_kernel(const int32_t* __restrict
         const int end = (last & gcl::kHaloMore) ? rowptr[rcl + 1] : 0;
         for (int e = rowptr[rcl] + gcl::kHaloRec; e < end; ++e) {
           const float wk = w[e];
-          const float4 v = mine[opos[e] * LPR];
+          const v4f v = *(lds4_t)(((unsigned)opos[e] << SH) + lb);
           a0 = __fmaf_rn(wk, v.x, a0);
           a1 = __fmaf_rn(wk, v.y, a1);
           a2 = __fmaf_rn(wk, v.z, a2);
@@ -409,11 +450,178 @@ __global__ __launch_bounds__(256) void agg_halo_kernel(const int32_t* __restrict
     if (row < n && cactive && !(last & gcl::kHaloSkip)) {
       a0 += bz0; a1 += bz1; a2 += bz2; a3 += bz3;
       float* __restrict__ yp = Yb + (int64_t)row * ldy + c0;
-      typedef float v4f __attribute__((ext_vector_type(4)));
       v4f v = {a0, a1, a2, a3};
       if (nt_store) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(yp));
       else *reinterpret_cast<v4f*>(yp) = v;
     }
+  }
+  GCL_AGG_STAMP(3)  // sums + stores issued
+#ifdef GCL_STAMPS
+  if (lane == 0 && (blockIdx.x * NW + wave) < 4096)
+    for (int i = 0; i < 8; ++i) agg_stamps[(blockIdx.x * NW + wave) * 8 + i] = st_acc[i];
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same aggregation with PERSISTENT blocks.  Stamps of agg_halo_kernel (tools/stamps_agg.py) put half of a
+// block's life before its last load is issued - kernel arguments, block -> (sample, tile) arithmetic, the tile's
+// list behind a scalar-load round trip - and LDS (one 31 KB image per block) caps a CU at five blocks, so that
+// start-up is paid in throughput.  Here a block walks items m = j, j + J, ... of its XCD group (one item = one
+// tile of one sample): arguments and addressing are set up once, the next item's list entries are fetched during
+// the current item's sums, and the stores of item i are still in flight while the loads of item i + 1 are issued.
+// One image per block, two barriers per item (loaded / free again).
+// ---------------------------------------------------------------------------------------------------------
+template <int LPR, int T, int MAXPW>
+__global__ __launch_bounds__(256) void agg_halo_loop_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ cnt,
+                                                            const int2* __restrict__ rec, const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ opos, const float* __restrict__ w,
+                                                            int32_t smax, const float* __restrict__ H, int64_t ldh,
+                                                            int64_t bsh, const float* __restrict__ bias,
+                                                            float* __restrict__ Y, int64_t ldy, int64_t bsy, int32_t n,
+                                                            int32_t B, int32_t F, int32_t ntiles, int32_t nt_store) {
+  extern __shared__ float4 img[];  // (smax + 1) * LPR float4: own rows, halo rows, zero row
+  constexpr int RPW = 64 / LPR;
+  constexpr int NIT = T / 4 / RPW;
+  constexpr int SH = LPR == 16 ? 8 : LPR == 32 ? 9 : 10;  // log2 of the bytes of an image row
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) const v4f* lds4_t;
+  const int xcd = blockIdx.x & (gcl::kNumXCD - 1);
+  const int J = gridDim.x >> 3;
+  int m = blockIdx.x >> 3;
+  const int nsamp = (B - xcd + gcl::kNumXCD - 1) / gcl::kNumXCD;  // samples of this XCD group: xcd, xcd + 8, ...
+  const int items = nsamp * ntiles;
+  if (m >= items) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane / LPR;
+  const int l = lane % LPR;
+  const int c0 = l * 4;
+  const bool cactive = c0 < F;
+  const unsigned cb = (unsigned)(cactive ? c0 : 0) * 4u;
+  const unsigned ldb = (unsigned)ldh * 4u;
+  const int hstride = smax - T;
+  const unsigned lb = (unsigned)(size_t)((gcl_lptr_t)img) + (unsigned)l * 16u;
+  const int zrow = smax << SH;
+
+  if (threadIdx.x < LPR) img[smax * LPR + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float bz0 = 0.f, bz1 = 0.f, bz2 = 0.f, bz3 = 0.f;
+  if (bias && cactive) {
+    const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
+    bz0 = bv.x; bz1 = bv.y; bz2 = bv.z; bz3 = bv.w;
+  }
+
+  // list entries of item mm for this wave's halo pieces (scalar loads: wave-uniform addresses)
+  auto fetch_list = [&](int mm, int (&jj)[MAXPW], int& nhalo) {
+    const int tile = mm % ntiles;
+    nhalo = cnt[tile] / RPW;
+    const int32_t* __restrict__ tl = list + (int64_t)tile * hstride;
+#pragma unroll
+    for (int q = 0; q < MAXPW; ++q) {
+      const int e0 = min((wave + 4 * q) * RPW, hstride - RPW);
+      int j = tl[e0];
+#pragma unroll
+      for (int r = 1; r < RPW; ++r) {
+        const int jr = tl[e0 + r];
+        j = sub == r ? jr : j;
+      }
+      jj[q] = j;
+    }
+  };
+  int jj[MAXPW], nhalo;
+  fetch_list(m, jj, nhalo);
+
+  while (true) {
+    const int s = m / ntiles;
+    const int tile = m - s * ntiles;
+    const int b = xcd + gcl::kNumXCD * s;
+    const char* Hc = reinterpret_cast<const char*>(H + (int64_t)b * bsh);
+    float* __restrict__ Yb = Y + (int64_t)b * bsy;
+    const int row0 = tile * T + wave * (T / 4) + sub;
+    // stage: own rows, halo rows (LDS-DMA), edge records (registers)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = row0 + it * RPW;
+      const char* src = Hc + (__umul24(row < n ? row : n - 1, ldb) + cb);
+      __builtin_amdgcn_global_load_lds((gcl_gptr_t)src, (gcl_lptr_t)(img + (wave * (T / 4) + it * RPW) * LPR), 16, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < MAXPW; ++q) {
+      const int p = wave + 4 * q;
+      if (p < nhalo) {
+        const char* src = Hc + (__umul24(jj[q], ldb) + cb);
+        __builtin_amdgcn_global_load_lds((gcl_gptr_t)src, (gcl_lptr_t)(img + (T + p * RPW) * LPR), 16, 0, 0);
+      }
+    }
+    int2 rc[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = row0 + it * RPW;
+      rc[it] = rec[(int64_t)(row < n ? row : n - 1) * gcl::kHaloRec + (l & (gcl::kHaloRec - 1))];
+    }
+    // next item's list: in flight during this item's sums
+    const int mn = m + J;
+    const bool more = mn < items;
+    if (more) fetch_list(mn, jj, nhalo);
+    __syncthreads();  // vmcnt(0) (this wave's DMA and records; the previous item's stores as well) + barrier: image complete
+
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = row0 + it * RPW;
+      const int rx = rc[it].x, rw = rc[it].y;
+      const int rxb = (rx & gcl::kHaloPosMask) << SH;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#define GCL_HALO_MULADD(K)                                          \
+  {                                                                 \
+    const unsigned ad = (unsigned)row_bcast<K>(rxb) + lb;           \
+    const float wk = __int_as_float(row_bcast<K>(rw));              \
+    const v4f v = *(lds4_t)ad;                                      \
+    a0 = mul_then_add(wk, v.x, a0);                                 \
+    a1 = mul_then_add(wk, v.y, a1);                                 \
+    a2 = mul_then_add(wk, v.z, a2);                                 \
+    a3 = mul_then_add(wk, v.w, a3);                                 \
+  }
+#define GCL_HALO_FMA(K)                                             \
+  {                                                                 \
+    const unsigned ad = (unsigned)row_bcast<K>(rxb) + lb;           \
+    const float wk = __int_as_float(row_bcast<K>(rw));              \
+    const v4f v = *(lds4_t)ad;                                      \
+    a0 = __fmaf_rn(wk, v.x, a0);                                    \
+    a1 = __fmaf_rn(wk, v.y, a1);                                    \
+    a2 = __fmaf_rn(wk, v.z, a2);                                    \
+    a3 = __fmaf_rn(wk, v.w, a3);                                    \
+  }
+      GCL_HALO_MULADD(0) GCL_HALO_MULADD(1) GCL_HALO_MULADD(2) GCL_HALO_MULADD(3)
+      GCL_HALO_MULADD(4) GCL_HALO_MULADD(5) GCL_HALO_MULADD(6) GCL_HALO_MULADD(7)
+      const int last = row_bcast<15>(rx);
+      if (__any(row_bcast<8>(rxb) != zrow)) {
+        GCL_HALO_FMA(8) GCL_HALO_FMA(9) GCL_HALO_FMA(10) GCL_HALO_FMA(11)
+        GCL_HALO_FMA(12) GCL_HALO_FMA(13) GCL_HALO_FMA(14) GCL_HALO_FMA(15)
+        if (__any((last & gcl::kHaloMore) != 0)) {
+          const int rcl = row < n ? row : n - 1;
+          const int end = (last & gcl::kHaloMore) ? rowptr[rcl + 1] : 0;
+          for (int e = rowptr[rcl] + gcl::kHaloRec; e < end; ++e) {
+            const float wk = w[e];
+            const v4f v = *(lds4_t)(((unsigned)opos[e] << SH) + lb);
+            a0 = __fmaf_rn(wk, v.x, a0);
+            a1 = __fmaf_rn(wk, v.y, a1);
+            a2 = __fmaf_rn(wk, v.z, a2);
+            a3 = __fmaf_rn(wk, v.w, a3);
+          }
+        }
+      }
+#undef GCL_HALO_MULADD
+#undef GCL_HALO_FMA
+      if (row < n && cactive && !(last & gcl::kHaloSkip)) {
+        a0 += bz0; a1 += bz1; a2 += bz2; a3 += bz3;
+        float* __restrict__ yp = Yb + (int64_t)row * ldy + c0;
+        v4f v = {a0, a1, a2, a3};
+        if (nt_store) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(yp));
+        else *reinterpret_cast<v4f*>(yp) = v;
+      }
+    }
+    if (!more) break;
+    m = mn;
+    __syncthreads();  // every wave is done reading the image
   }
 }
 
@@ -437,32 +645,74 @@ int launch_agg_halo(const AggArgs& ga, const float* h, int64_t ldh, int64_t bsh,
   static const int force_t = agg_env("GCL_AGG_HALO_T", 0);
   static const int nt = agg_env("GCL_AGG_NT", 1);
   if (!enabled || ga.ell_width != 8) return -1;  // the arithmetic below is that of agg_kernel<.., EW = 8>
+  if ((int64_t)n * ldh * 4 >= (int64_t)1 << 31 || ldh * 4 >= (int64_t)1 << 24 || n >= 1 << 24) return -1;  // 32-bit row offsets
   constexpr int RPW = 64 / LPR;
   const gcl_halo* hl = nullptr;
   for (int t = 0; t < 2; ++t) {
     const gcl_halo& c = ga.halo[t];
     if (c.T == 0 || (force_t && c.T != force_t)) continue;
     const int64_t lds = (int64_t)(c.smax + 1) * LPR * 16;
-    if (lds > (c.T == 64 ? 40 : 53) * 1024 || gcl::cdiv(c.smax / RPW, 4) > 32) continue;
+    if (lds > (c.T == 64 ? 40 : 53) * 1024 || gcl::cdiv((c.smax - c.T) / RPW, 4) > 32) continue;
     hl = &c;
     break;
   }
   if (!hl) return -1;
   const int64_t lds = (int64_t)(hl->smax + 1) * LPR * 16;
-  const int maxpw = (int)gcl::cdiv(hl->smax / RPW, 4);
+  int nw = agg_env("GCL_AGG_HALO_NW", 8);  // waves per block (tile): more waves = shorter block life at the same LDS
+  nw = (nw == 16 && hl->T / 16 >= RPW) ? 16 : (nw >= 8 && hl->T / 8 >= RPW) ? 8 : 4;
+  const int maxpw = (int)gcl::cdiv((hl->smax - hl->T) / RPW, nw);
+  const int skew = agg_env("GCL_AGG_HALO_SKEW", 0);
+  const int loop = agg_env("GCL_AGG_HALO_LOOP", 1);
+  if (loop && lds <= 64 * 1024) {
+    // persistent form: blocks per CU by LDS, every block walks its share of the (sample, tile) items of its XCD group
+    const int per_cu = (int)std::min<int64_t>(8, (160 * 1024) / lds);
+    const int bpc = agg_env("GCL_AGG_HALO_BPC", per_cu);
+    const int J = 32 * bpc;  // blocks per XCD
+    dim3 pgrid((unsigned)(gcl::kNumXCD * J)), pblock(256);
+    auto go = [&](auto kern) -> int {
+      hipLaunchKernelGGL(kern, pgrid, pblock, (size_t)lds, st, hl->list, hl->cnt, reinterpret_cast<const int2*>(hl->rec),
+                         ga.rowptr, hl->opos, ga.w, hl->smax, h, ldh, bsh, bias, y, ldy, bsy, n, B, F, hl->ntiles, nt);
+      return GCL_OK;
+    };
+    const int mp4 = (int)gcl::cdiv((hl->smax - hl->T) / RPW, 4);  // this kernel runs 4 waves per block
+    if (hl->T == 64)
+      mp4 <= 4 ? go(&agg_halo_loop_kernel<LPR, 64, 4>) : mp4 <= 8 ? go(&agg_halo_loop_kernel<LPR, 64, 8>)
+          : mp4 <= 16 ? go(&agg_halo_loop_kernel<LPR, 64, 16>) : go(&agg_halo_loop_kernel<LPR, 64, 32>);
+    else
+      mp4 <= 4 ? go(&agg_halo_loop_kernel<LPR, 32, 4>) : mp4 <= 8 ? go(&agg_halo_loop_kernel<LPR, 32, 8>)
+          : mp4 <= 16 ? go(&agg_halo_loop_kernel<LPR, 32, 16>) : go(&agg_halo_loop_kernel<LPR, 32, 32>);
+    GCL_CHECK_LAUNCH();
+    return GCL_OK;
+  }
   const int xcd_map = B >= gcl::kNumXCD ? 1 : 0;
   const int64_t nb = xcd_map ? (int64_t)gcl::kNumXCD * gcl::cdiv(B, gcl::kNumXCD) * hl->ntiles : (int64_t)B * hl->ntiles;
   GCL_CHECK_ARG(nb < (int64_t)INT32_MAX, "aggregate: grid too large");
-  dim3 grid((unsigned)nb), block(256);
-#define GCL_HALO_L(T_, MP_)                                                                                        \
-  hipLaunchKernelGGL((agg_halo_kernel<LPR, T_, MP_>), grid, block, (size_t)lds, st, hl->list, hl->cnt,               \
-                     reinterpret_cast<const int2*>(hl->rec), ga.rowptr, hl->opos, ga.w, hl->smax, h, ldh, bsh, bias, \
-                     y, ldy, bsy, n, B, F, hl->ntiles, xcd_map, nt)
-#define GCL_HALO_T(T_)                   \
-  do {                                   \
-    if (maxpw <= 8) GCL_HALO_L(T_, 8);   \
-    else if (maxpw <= 16) GCL_HALO_L(T_, 16); \
-    else GCL_HALO_L(T_, 32);             \
+  dim3 grid((unsigned)nb);
+#define GCL_HALO_L(T_, MP_, NW_)                                                                                          \
+  do {                                                                                                                   \
+    if constexpr ((T_) / (NW_) >= RPW)                                                                                   \
+      hipLaunchKernelGGL((agg_halo_kernel<LPR, T_, MP_, NW_>), grid, dim3(64 * NW_), (size_t)lds, st, hl->list, hl->cnt,  \
+                         reinterpret_cast<const int2*>(hl->rec), ga.rowptr, hl->opos, ga.w, hl->smax, h, ldh, bsh, bias,  \
+                         y, ldy, bsy, n, B, F, hl->ntiles, xcd_map, nt, skew);                                            \
+  } while (0)
+#define GCL_HALO_T(T_)                                        \
+  do {                                                        \
+    if (nw == 16) {                                           \
+      if (maxpw <= 1) GCL_HALO_L(T_, 1, 16);                  \
+      else if (maxpw <= 2) GCL_HALO_L(T_, 2, 16);             \
+      else if (maxpw <= 4) GCL_HALO_L(T_, 4, 16);             \
+      else GCL_HALO_L(T_, 8, 16);                             \
+    } else if (nw == 8) {                                     \
+      if (maxpw <= 2) GCL_HALO_L(T_, 2, 8);                   \
+      else if (maxpw <= 4) GCL_HALO_L(T_, 4, 8);              \
+      else if (maxpw <= 8) GCL_HALO_L(T_, 8, 8);              \
+      else GCL_HALO_L(T_, 16, 8);                             \
+    } else {                                                  \
+      if (maxpw <= 4) GCL_HALO_L(T_, 4, 4);                   \
+      else if (maxpw <= 8) GCL_HALO_L(T_, 8, 4);              \
+      else if (maxpw <= 16) GCL_HALO_L(T_, 16, 4);            \
+      else GCL_HALO_L(T_, 32, 4);                             \
+    }                                                         \
   } while (0)
   if (hl->T == 64) GCL_HALO_T(64);
   else GCL_HALO_T(32);

@@ -46,8 +46,8 @@ constexpr int kNumCU = 256;
 constexpr int kEll = 8;      // stride of the ELL prefix arrays
 constexpr int kHeavy = 64;   // rows with more edges than this get a whole block
 constexpr int kHaloRec = 16;             // edge records per row held in registers (one per lane of a 16-lane row group)
-constexpr int kHaloMore = 1 << 30;       // flag in slot 15: the row has more than 16 edges (finish from the CSR arrays)
-constexpr int kHaloSkip = 1 << 29;       // flag in slot 15: heavy row, done by agg_heavy_kernel (do not store)
+constexpr int kHaloMore = 1 << 17;       // flag in slot 15: the row has more than 16 edges (finish from the CSR arrays)
+constexpr int kHaloSkip = 1 << 16;       // flag in slot 15: heavy row, done by agg_heavy_kernel (do not store)
 constexpr int kHaloPosMask = 0xFFFF;
 
 __device__ __forceinline__ float prelu_f(float x, float a) { return x > 0.f ? x : a * x; }
@@ -70,6 +70,11 @@ int launch_reduce_parts(const float* part, int nparts, int64_t pstride, int pld,
 int launch_reduce_parts2(const float* part, int nparts, int64_t pstride, int pld, int off1, float* out0, float* out1,
                          int C, int accumulate, hipStream_t st);
 
+// Kernels that ask for more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised first.
+// The attribute belongs to the (function, DEVICE) pair, so the "already done" record is kept per device: a process
+// that drives several GPUs (or a later hipSetDevice) sets it again where it is still missing.
+int ensure_dyn_lds(const void* func, size_t bytes);
+
 int launch_reduce_parts3(const float* part, int nparts, int64_t pstride, int pld, float* out0, int acc0, float* out1,
                          int acc1, float* out2, int acc2, int C, hipStream_t st);
 
@@ -81,9 +86,9 @@ int launch_reduce_parts3(const float* part, int nparts, int64_t pstride, int pld
 // when the graph is created, and only when the tiling shares sources well enough to pay (graph.hip).
 struct gcl_halo {
   int32_t T = 0, ntiles = 0;
-  int32_t smax = 0;          // stride of `list` = largest per-tile source count, rounded up to 8; image row `smax` is the zero row
-  int32_t* list = nullptr;   // [ntiles * smax] distinct source rows of a tile, ascending, padded by repeating the last one
-  int32_t* cnt = nullptr;    // [ntiles] entries to stage (multiple of 8)
+  int32_t smax = 0;          // rows of a tile image: T own rows + the largest halo count (rounded up to 8); row `smax` is the zero row
+  int32_t* list = nullptr;   // [ntiles * (smax - T)] sources of a tile OUTSIDE the tile (its halo), ascending, padded by repeating the last
+  int32_t* cnt = nullptr;    // [ntiles] halo entries to stage (multiple of 8)
   int32_t* rec = nullptr;    // [n * 16 * 2] {image position | flags (slot 15), weight bits} of the first 16 edges of a row
   int32_t* opos = nullptr;   // [E'] image position of every CSR slot (rows with more than 16 edges)
 };

@@ -5,6 +5,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -16,6 +19,22 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+}  // namespace gcl
+
+namespace gcl {
+int ensure_dyn_lds(const void* func, size_t bytes) {
+  if (bytes <= 64 * 1024) return GCL_OK;
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> done;
+  int dev = 0;
+  GCL_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = done[{func, dev}];
+  if (have >= bytes) return GCL_OK;
+  GCL_CHECK_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  have = bytes;
+  return GCL_OK;
 }
 }  // namespace gcl
 
@@ -142,33 +161,39 @@ bool build_halo_host(const std::vector<int32_t>& rp, const std::vector<int32_t>&
                      int32_t n, int32_t T, HaloHost& h) {
   const int32_t ntiles = (int32_t)gcl::cdiv(n, T);
   if (ntiles < 2) return false;
+  // a tile's image holds its own T rows at positions [0, T) (staged without any list) and then the sources
+  // outside the tile (the halo list), ascending
   std::vector<int32_t> mark(n, -1);
   std::vector<std::vector<int32_t>> src(ntiles);
-  int64_t edges = 0, distinct = 0;
-  int32_t max_s = 0;
+  int64_t edges = 0, staged = 0;
+  int32_t max_h = 0;
   for (int32_t t = 0; t < ntiles; ++t) {
     auto& sv = src[t];
-    for (int32_t i = t * T; i < n && i < (t + 1) * T; ++i) {
+    const int32_t lo = t * T, hi = (t + 1) * T;
+    for (int32_t i = lo; i < n && i < hi; ++i) {
       const int32_t d = rp[i + 1] - rp[i];
       if (d > gcl::kHeavy) continue;  // heavy rows read global memory in their own kernel
       edges += d;
-      for (int32_t e = rp[i]; e < rp[i + 1]; ++e)
-        if (mark[cl[e]] != t) {
-          mark[cl[e]] = t;
-          sv.push_back(cl[e]);
+      for (int32_t e = rp[i]; e < rp[i + 1]; ++e) {
+        const int32_t j = cl[e];
+        if ((j < lo || j >= hi) && mark[j] != t) {
+          mark[j] = t;
+          sv.push_back(j);
         }
+      }
     }
     std::sort(sv.begin(), sv.end());
-    distinct += (int64_t)sv.size();
-    if ((int32_t)sv.size() > max_s) max_s = (int32_t)sv.size();
+    staged += T + (int64_t)sv.size();
+    if ((int32_t)sv.size() > max_h) max_h = (int32_t)sv.size();
   }
-  if (distinct == 0 || edges * 10 < distinct * 16) return false;
-  const int32_t smax = (max_s + 7) / 8 * 8;
-  if (smax > 1024 || smax >= gcl::kHaloPosMask) return false;
+  if (edges * 10 < staged * 16) return false;
+  const int32_t hstride = max_h > 0 ? (max_h + 7) / 8 * 8 : 8;
+  const int32_t smax = T + hstride;
+  if (smax > 1024) return false;
   h.T = T;
   h.ntiles = ntiles;
   h.smax = smax;
-  h.list.assign((size_t)ntiles * smax, 0);
+  h.list.assign((size_t)ntiles * hstride, 0);
   h.cnt.assign(ntiles, 0);
   h.rec.assign((size_t)n * gcl::kHaloRec * 2, 0);
   h.opos.assign(cl.size(), smax);
@@ -176,10 +201,12 @@ bool build_halo_host(const std::vector<int32_t>& rp, const std::vector<int32_t>&
   for (int32_t t = 0; t < ntiles; ++t) {
     const auto& sv = src[t];
     const int32_t c = (int32_t)sv.size();
-    for (int32_t k = 0; k < smax; ++k) h.list[(size_t)t * smax + k] = c ? sv[k < c ? k : c - 1] : 0;
+    const int32_t lo = t * T, hi = (t + 1) * T;
+    for (int32_t k = 0; k < hstride; ++k) h.list[(size_t)t * hstride + k] = c ? sv[k < c ? k : c - 1] : lo;
     h.cnt[t] = (c + 7) / 8 * 8;
-    for (int32_t k = 0; k < c; ++k) posof[sv[k]] = k;
-    for (int32_t i = t * T; i < n && i < (t + 1) * T; ++i) {
+    for (int32_t k = 0; k < c; ++k) posof[sv[k]] = T + k;
+    auto pos = [&](int32_t j) { return (j >= lo && j < hi) ? j - lo : posof[j]; };
+    for (int32_t i = lo; i < n && i < hi; ++i) {
       const int32_t d = rp[i + 1] - rp[i];
       const bool heavy = d > gcl::kHeavy;
       int32_t* r = &h.rec[(size_t)i * gcl::kHaloRec * 2];
@@ -188,13 +215,13 @@ bool build_halo_host(const std::vector<int32_t>& rp, const std::vector<int32_t>&
         float wv = in ? ww[rp[i] + k] : 0.f;
         int32_t wb;
         memcpy(&wb, &wv, 4);
-        r[2 * k] = in ? posof[cl[rp[i] + k]] : smax;
+        r[2 * k] = in ? pos(cl[rp[i] + k]) : smax;
         r[2 * k + 1] = wb;
       }
       if (heavy) r[2 * (gcl::kHaloRec - 1)] |= gcl::kHaloSkip;
       else if (d > gcl::kHaloRec) r[2 * (gcl::kHaloRec - 1)] |= gcl::kHaloMore;
       if (!heavy)
-        for (int32_t e = rp[i]; e < rp[i + 1]; ++e) h.opos[e] = posof[cl[e]];
+        for (int32_t e = rp[i]; e < rp[i + 1]; ++e) h.opos[e] = pos(cl[e]);
     }
   }
   return true;

@@ -300,7 +300,7 @@ def prune_mesh_to_region(
     return out
 
 
-def tile_order(points: np.ndarray, leaf: int = 64) -> np.ndarray:
+def tile_order(points: np.ndarray, leaf: int = 64, degree: np.ndarray = None) -> np.ndarray:
     """Node order in which every run of `leaf` consecutive nodes is a spatially compact patch: recursive
     coordinate bisection along the widest axis, cut at multiples of `leaf` (ties broken by the original index,
     so the result is deterministic).  Returns `order` with `order[new] = old`.
@@ -309,13 +309,18 @@ def tile_order(points: np.ndarray, leaf: int = 64) -> np.ndarray:
     model (inputs and outputs live on grid nodes, src/models.py:808-874).  With this order the neighbours of a
     64-row tile of the mesh graph are 108 distinct rows instead of 211 in creation order, which is what lets the
     aggregation stage a tile's sources once in LDS (csrc/aggregate.hip, agg_halo_kernel).  Each row keeps the
-    order of its in-edges, so every sum runs in the reference's order and results are unchanged bit for bit."""
+    order of its in-edges, so every sum runs in the reference's order and results are unchanged bit for bit.
+    With `degree` the nodes of a patch are listed by descending degree: the few high-degree nodes (the 642 coarse
+    vertices of a [3, 5] mesh have 12 neighbours, the rest 6) then share row groups instead of each dragging three
+    ordinary rows through the long-row path."""
     pts = np.asarray(points, dtype=np.float64)
     out = []
     stack = [np.arange(len(pts))]
     while stack:
         ids = stack.pop()
         if len(ids) <= leaf:
+            if degree is not None:
+                ids = ids[np.lexsort((ids, -np.asarray(degree)[ids]))]
             out.append(ids)
             continue
         p = pts[ids]

@@ -42,7 +42,7 @@ from .create_graphs import (create_decoding_graph, create_encoding_graph, create
                             create_product_graph)
 from .functional import (AssembleFn, EdgeLayout, GATLayerFn, Gather2Fn, GCNStackFn, GradLanding, GraphNormFn, InteractionNetFn,
                          LayerNormFn, MeanAggFn, MeshLatFn, MLPFn)
-from .mesh import get_hierarchy_of_triangular_meshes_for_sphere, get_mesh_lat_long, prune_mesh_to_region
+from .mesh import get_hierarchy_of_triangular_meshes_for_sphere, get_mesh_lat_long, prune_mesh_to_region, tile_order
 
 
 # ------------------------------------------------------------------------------------------------
@@ -578,6 +578,43 @@ class WeatherPrediction(nn.Module):
 
         return ok(self.encoder) and ok(self.decoder) and getattr(self, "compact", True)
 
+    # --------------------------------------------------------------------------------------------
+    # Mesh rows in tile order (compact pipeline, GCN processor).  Mesh nodes never leave the model, so the processor
+    # may number its rows freely: rows are listed patch by patch (mesh.tile_order), the permutation rides in the row
+    # maps of the two stage gathers that exist anyway, and the processing graph is the reference's edge list with
+    # renamed end points - every row keeps the order of its in-edges, so each sum runs in the reference's order.
+    # What it buys: a 64-row tile of the [3, 5] mesh reads 108 distinct source rows instead of 211, which lets the
+    # aggregation stage a tile's sources once in LDS (gcl_graph_halo_info, csrc/aggregate.hip).
+    # --------------------------------------------------------------------------------------------
+    _renumber_mesh = os.environ.get("GCL_NO_RENUMBER", "0") in ("0", "")
+
+    def _mesh_order(self):
+        """(order, pos) int64 CPU tensors: order[new] = old, pos[old] = new; None when the processor keeps the
+        reference numbering (any processor but a GCN stack; GCL_NO_RENUMBER=1)."""
+        if not self._renumber_mesh or self.processor.graph_layer.layer_type != GraphLayerType.ConvGCN:
+            return None
+        cached = getattr(self, "_mesh_perm", None)
+        if cached is None:
+            M = self._num_mesh_nodes
+            ei = self.processing_graph.detach().cpu()
+            deg = torch.bincount(ei[1], minlength=M).numpy()
+            order = torch.from_numpy(np.ascontiguousarray(tile_order(self._finest_mesh.vertices, 64, degree=deg))).to(torch.int64)
+            pos = torch.empty(M, dtype=torch.int64)
+            pos[order] = torch.arange(M)
+            cached = self._mesh_perm = (order, pos)
+        return cached
+
+    def _processing_graph_tiled(self):
+        """The processing graph with mesh nodes renamed to tile order (same edge order); rebuilt only when
+        `processing_graph` is replaced or modified."""
+        g = self.processing_graph
+        key = (id(g), g._version)
+        c = getattr(self, "_proc_tiled", None)
+        if c is None or c[0] != key:
+            _, pos = self._mesh_order()
+            c = self._proc_tiled = (key, pos.to(g.device)[g], g)  # keep g alive: its id must not be reused
+        return c[1]
+
     def _compact_setup(self, device):
         G, M = self._num_grid_nodes, self._num_mesh_nodes
         enc, dec = self.encoding_graph.cpu(), self.decoding_graph.cpu()
@@ -610,7 +647,13 @@ class WeatherPrediction(nn.Module):
         map_b[mi] = torch.arange(Mi)
         inv_a = torch.full((G + Md,), -1, dtype=torch.int64)
         inv_a[G:] = md
-        c.maps_mesh = (i32(map_a), i32(map_b), i32(inv_a), i32(mi))
+        perm = self._mesh_order()
+        c.perm = perm
+        if perm is not None:  # mesh rows of the processor are in tile order: forward maps are indexed by the NEW row
+            order, pos = perm
+            map_a, map_b = map_a[order], map_b[order]
+            inv_a[G:] = pos[md]
+        c.maps_mesh = (i32(map_a), i32(map_b), i32(inv_a), i32(mi if perm is None else perm[1][mi]))
         # decoder input [G+U] <- encoder compact output (a: grid rows) | processed mesh [M] (b)
         dmap_a = torch.full((G + U,), -1, dtype=torch.int64)
         dmap_a[:G] = torch.arange(G)
@@ -620,6 +663,9 @@ class WeatherPrediction(nn.Module):
         dinv_a[:G] = torch.arange(G)
         dinv_b = torch.full((M,), -1, dtype=torch.int64)
         dinv_b[used] = G + torch.arange(U)
+        if perm is not None:
+            dmap_b[G:] = perm[1][used]
+            dinv_b = dinv_b[perm[0]]
         c.maps_dec = (i32(dmap_a), i32(dmap_b), i32(dinv_a), i32(dinv_b))
         c.fold = {}
         c.mi = mi
@@ -649,6 +695,9 @@ class WeatherPrediction(nn.Module):
         map_b[c.mi] = (j // r) * ne + G + Md + (j % r)
         inv_fold = torch.full((B * r,), -1, dtype=torch.int64)
         inv_fold[:Mi] = c.mi
+        if c.perm is not None:
+            map_b = map_b[c.perm[0]]
+            inv_fold[:Mi] = c.perm[1][c.mi]
         f.maps = (c.maps_mesh[0], i32(map_b), c.maps_mesh[2], i32(inv_fold))
         # decoder-input maps: the encoder output now has ne rows per sample, the folded ones feed nothing there
         dinv_a = torch.cat([c.maps_dec[2], torch.full((r,), -1, dtype=torch.int32, device=device)]).contiguous()
@@ -689,19 +738,24 @@ class WeatherPrediction(nn.Module):
                                                attention_threshold=attention_threshold,
                                                edge_attr=self._processing_edge_features)
         else:
-            processed = self.processor.forward(X=mesh_lat, edge_index=self.processing_graph,
-                                               attention_threshold=attention_threshold,
+            pg = self._processing_graph_tiled() if c.perm is not None else self.processing_graph
+            processed = self.processor.forward(X=mesh_lat, edge_index=pg, attention_threshold=attention_threshold,
                                                **({"_grad_src": land} if land is not None else {}))
         dec_in = Gather2Fn.apply(enc_c, processed, maps_dec, G + c.U, B, land)      # [B, G+U, D]
         gcn_dec = self.decoder.graph_layer.layer_type == GraphLayerType.ConvGCN
         decoded = self.decoder.forward(X=dec_in, edge_index=c.dec_graph, **({"_out_rows": G} if gcn_dec else {}))
         out, grid_lat = (decoded if gcn_dec else decoded[:, :G, :]), enc_c[:, :G, :]
+        if c.perm is not None and not self._want_prediction_only:
+            processed = processed.index_select(1, c.perm[1].to(processed.device))  # callers see reference row order
         if squeeze:
             return out[0], grid_lat[0], processed[0]
         return out, grid_lat, processed
 
+    _want_prediction_only = False
+
     def forward_with_latents(self, X: torch.Tensor, attention_threshold=0.0, **kwargs):
         landing = kwargs.pop("_landing", False)
+        self._want_prediction_only = landing  # forward(): the mesh latents are dropped, so they stay in tile order
         if self._compact_eligible():
             return self._forward_compact(X, attention_threshold, _landing=landing, **kwargs)
         G = self._num_grid_nodes

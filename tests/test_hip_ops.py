@@ -286,6 +286,81 @@ def test_gcn_aggregate_mesh(hip, levels, F, B):
     assert rel(dh, hr.grad) < TOL
 
 
+def _tiled(g, leaf=64):
+    """The mesh graph with nodes renamed to tile order (what models.WeatherPrediction hands the processor)."""
+    from graphcast_lite_amd.mesh import tile_order
+
+    n = g["M"]
+    deg = torch.bincount(g["proc"][1], minlength=n).numpy()
+    order = torch.from_numpy(np.ascontiguousarray(tile_order(g["mesh"].vertices, leaf, degree=deg)))
+    pos = torch.empty(n, dtype=torch.int64)
+    pos[order] = torch.arange(n)
+    return pos[g["proc"]], order, pos
+
+
+@pytest.mark.parametrize("levels,F,B", [([3, 5], 64, 9), ([3, 5], 64, 64), ([3, 5], 48, 3), ([2, 4], 64, 17), ([3, 5], 128, 2),
+                                        ([2, 3], 64, 8)])
+def test_gcn_aggregate_source_tiles(hip, levels, F, B, monkeypatch):
+    """Mesh rows in tile order: gcl_aggregate stages a tile's distinct source rows once in LDS (agg_halo_kernel,
+    include/gcl.h: gcl_graph_halo_info).  Against the oracle on the renamed graph, un-renamed against the oracle
+    on the reference graph (renaming must be invisible), and BIT-equal to the per-edge gather kernel, forward and
+    transposed, with and without bias."""
+    g = build_graphs(experiment("baseline", mesh_levels=levels))
+    n = g["M"]
+    ei_t, order, pos = _tiled(g)
+    G = hip.Graph(ei_t, n, hip.GRAPH_GCN)
+    assert G.halo_info(False, 64) is not None and G.halo_info(True, 64) is not None, "tile order must enable the source-tile layout"
+    h, b = rnd(B, n, F, seed=1), rnd(F, seed=2)
+    e_ref, w_ref = P.gcn_norm(g["proc"], n, torch.float32)
+    ref = P._propagate_sum(h, e_ref, w_ref, n) + b          # reference numbering
+    for tr, bias in ((False, b), (True, None)):
+        outs = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("GCL_AGG_HALO", mode)
+            outs[mode] = hip.aggregate(G, h[:, order].contiguous().to(DEV), None if bias is None else bias.to(DEV), transpose=tr).cpu()
+        assert torch.equal(outs["1"], outs["0"]), "source-tile kernel and per-edge kernel differ in some bit"
+        if not tr:
+            assert rel(outs["1"][:, pos], ref) < TOL
+        else:
+            hr = h.clone().requires_grad_()
+            P._propagate_sum(hr, e_ref, w_ref, n).backward(h)
+            assert rel(outs["1"][:, pos], hr.grad) < TOL
+
+
+def test_gcn_aggregate_source_tiles_long_rows(hip, monkeypatch):
+    """Rows beyond the 16 edge records a lane group holds (finished from the CSR arrays), heavy rows (> 64 edges: their
+    own kernel), a ragged last tile and non-finite inputs next to padded slots: a ring lattice (6 neighbours) with a
+    few long rows.  Bit-equal to the per-edge kernel and within tolerance of the oracle."""
+    rng = np.random.default_rng(7)
+    n = 64 * 37 + 19
+    idx = np.arange(n)
+    src = np.concatenate([(idx + d) % n for d in (-3, -2, -1, 1, 2, 3)])
+    dst = np.tile(idx, 6)
+    extra_s, extra_d = [], []
+    for r, d in ((100, 20), (101, 40), (777, 17), (1500, 90), (n - 1, 30)):
+        nb = (r + rng.choice(np.arange(4, 200), size=d - 7, replace=False) * rng.choice([-1, 1], size=d - 7)) % n
+        extra_s.append(nb); extra_d.append(np.full(nb.size, r))
+    ei = torch.from_numpy(np.stack([np.concatenate([src] + extra_s), np.concatenate([dst] + extra_d)]).astype(np.int64))
+    G = hip.Graph(ei, n, hip.GRAPH_GCN)
+    assert G.halo_info(False, 64) is not None and G.max_in_degree > 64
+    B, F = 5, 64
+    h = rnd(B, n, F, seed=4)
+    h[0, 9, 3] = float("inf")  # must reach only the rows that really read row 9
+    e2, w = P.gcn_norm(ei, n, torch.float32)
+    ref = P._propagate_sum(h, e2, w, n)
+    for tr in (False, True):
+        outs = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("GCL_AGG_HALO", mode)
+            outs[mode] = hip.aggregate(G, h.to(DEV), None, transpose=tr).cpu()
+        assert torch.equal(outs["1"].view(torch.int32), outs["0"].view(torch.int32))
+    fin = torch.isfinite(ref)
+    monkeypatch.setenv("GCL_AGG_HALO", "1")
+    y = hip.aggregate(G, h.to(DEV), None).cpu()
+    assert torch.equal(torch.isfinite(y), fin)
+    assert rel(torch.where(fin, y, torch.zeros(())), torch.where(fin, ref, torch.zeros(()))) < TOL
+
+
 def test_gcn_aggregate_bipartite_and_padded_ld(hip):
     """Encoder (skewed in-degree, most rows self-loop only) and decoder graphs, padded scratch input."""
     g = build_graphs(experiment("baseline", mesh_levels=[3, 5]))
