@@ -466,13 +466,16 @@ __global__ __launch_bounds__(64 * NW) void agg_halo_kernel(const int32_t* __rest
 // The same aggregation with PERSISTENT blocks.  Stamps of agg_halo_kernel (tools/stamps_agg.py) put half of a
 // block's life before its last load is issued - kernel arguments, block -> (sample, tile) arithmetic, the tile's
 // list behind a scalar-load round trip - and LDS (one 31 KB image per block) caps a CU at five blocks, so that
-// start-up is paid in throughput.  Here a block walks items m = j, j + J, ... of its XCD group (one item = one
-// tile of one sample): arguments and addressing are set up once, the next item's list entries are fetched during
-// the current item's sums, and the stores of item i are still in flight while the loads of item i + 1 are issued.
-// One image per block, two barriers per item (loaded / free again).
+// start-up is paid in throughput.  A probe with the kernel's structure (tools/probes/tile_copy_probe.hip) adds
+// that re-reading a tile's edge records (128 B per row) for every sample costs 17 us of a 67 us launch and the
+// scalar-loaded list 6 us, although both are the same for all samples.  So a block here walks a CONTIGUOUS range
+// of the (tile, sample) items of its XCD group, tile-major: arguments and addressing are set up once, a tile's
+// list entries and edge records are fetched once and kept in registers for all of the group's samples, and the
+// stores of one item are still in flight while the loads of the next are issued.  One image per block, two
+// barriers per item (loaded / free again).
 // ---------------------------------------------------------------------------------------------------------
-template <int LPR, int T, int MAXPW>
-__global__ __launch_bounds__(256) void agg_halo_loop_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ cnt,
+template <int LPR, int T, int MAXPW, int NW, bool FMA8>
+__global__ __launch_bounds__(64 * NW) void agg_halo_loop_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ cnt,
                                                             const int2* __restrict__ rec, const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ opos, const float* __restrict__ w,
                                                             int32_t smax, const float* __restrict__ H, int64_t ldh,
@@ -481,16 +484,19 @@ __global__ __launch_bounds__(256) void agg_halo_loop_kernel(const int32_t* __res
                                                             int32_t B, int32_t F, int32_t ntiles, int32_t nt_store) {
   extern __shared__ float4 img[];  // (smax + 1) * LPR float4: own rows, halo rows, zero row
   constexpr int RPW = 64 / LPR;
-  constexpr int NIT = T / 4 / RPW;
+  constexpr int NIT = T / NW / RPW;
   constexpr int SH = LPR == 16 ? 8 : LPR == 32 ? 9 : 10;  // log2 of the bytes of an image row
   typedef float v4f __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) const v4f* lds4_t;
   const int xcd = blockIdx.x & (gcl::kNumXCD - 1);
-  const int J = gridDim.x >> 3;
-  int m = blockIdx.x >> 3;
+  const int J = gridDim.x >> 3, j = blockIdx.x >> 3;
   const int nsamp = (B - xcd + gcl::kNumXCD - 1) / gcl::kNumXCD;  // samples of this XCD group: xcd, xcd + 8, ...
-  const int items = nsamp * ntiles;
-  if (m >= items) return;
+  const int items = nsamp * ntiles;                               // item = tile * nsamp + sample index
+  // contiguous share of block j: items [m, mend) (the first items % J blocks take one more)
+  const int base = items / J, extra = items - base * J;
+  int m = j * base + min(j, extra);
+  const int mend = m + base + (j < extra ? 1 : 0);
+  if (m >= mend) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sub = lane / LPR;
@@ -510,14 +516,13 @@ __global__ __launch_bounds__(256) void agg_halo_loop_kernel(const int32_t* __res
     bz0 = bv.x; bz1 = bv.y; bz2 = bv.z; bz3 = bv.w;
   }
 
-  // list entries of item mm for this wave's halo pieces (scalar loads: wave-uniform addresses)
-  auto fetch_list = [&](int mm, int (&jj)[MAXPW], int& nhalo) {
-    const int tile = mm % ntiles;
+  // list entries of a tile for this wave's halo pieces (scalar loads: wave-uniform addresses)
+  auto fetch_list = [&](int tile, int (&jj)[MAXPW], int& nhalo) {
     nhalo = cnt[tile] / RPW;
     const int32_t* __restrict__ tl = list + (int64_t)tile * hstride;
 #pragma unroll
     for (int q = 0; q < MAXPW; ++q) {
-      const int e0 = min((wave + 4 * q) * RPW, hstride - RPW);
+      const int e0 = min((wave + NW * q) * RPW, hstride - RPW);
       int j = tl[e0];
 #pragma unroll
       for (int r = 1; r < RPW; ++r) {
@@ -527,42 +532,47 @@ __global__ __launch_bounds__(256) void agg_halo_loop_kernel(const int32_t* __res
       jj[q] = j;
     }
   };
-  int jj[MAXPW], nhalo;
-  fetch_list(m, jj, nhalo);
+  int jj[MAXPW], nhalo = 0, tile = -1;
+  int2 rc[NIT];
+#ifdef GCL_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
 
   while (true) {
-    const int s = m / ntiles;
-    const int tile = m - s * ntiles;
+    const int tnew = m / nsamp;
+    const int s = m - tnew * nsamp;
     const int b = xcd + gcl::kNumXCD * s;
+    if (tnew != tile) {  // wave-uniform: a new tile - its list entries and edge records serve all samples of the group
+      tile = tnew;
+      fetch_list(tile, jj, nhalo);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = tile * T + wave * (T / NW) + sub + it * RPW;
+        rc[it] = rec[(int64_t)(row < n ? row : n - 1) * gcl::kHaloRec + (l & (gcl::kHaloRec - 1))];
+      }
+    }
+    GCL_AGG_STAMP(0)  // new tile: list + records
     const char* Hc = reinterpret_cast<const char*>(H + (int64_t)b * bsh);
     float* __restrict__ Yb = Y + (int64_t)b * bsy;
-    const int row0 = tile * T + wave * (T / 4) + sub;
-    // stage: own rows, halo rows (LDS-DMA), edge records (registers)
+    const int row0 = tile * T + wave * (T / NW) + sub;
+    // stage: own rows, halo rows (LDS-DMA)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int row = row0 + it * RPW;
       const char* src = Hc + (__umul24(row < n ? row : n - 1, ldb) + cb);
-      __builtin_amdgcn_global_load_lds((gcl_gptr_t)src, (gcl_lptr_t)(img + (wave * (T / 4) + it * RPW) * LPR), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gcl_gptr_t)src, (gcl_lptr_t)(img + (wave * (T / NW) + it * RPW) * LPR), 16, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < MAXPW; ++q) {
-      const int p = wave + 4 * q;
+      const int p = wave + NW * q;
       if (p < nhalo) {
         const char* src = Hc + (__umul24(jj[q], ldb) + cb);
         __builtin_amdgcn_global_load_lds((gcl_gptr_t)src, (gcl_lptr_t)(img + (T + p * RPW) * LPR), 16, 0, 0);
       }
     }
-    int2 rc[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int row = row0 + it * RPW;
-      rc[it] = rec[(int64_t)(row < n ? row : n - 1) * gcl::kHaloRec + (l & (gcl::kHaloRec - 1))];
-    }
-    // next item's list: in flight during this item's sums
-    const int mn = m + J;
-    const bool more = mn < items;
-    if (more) fetch_list(mn, jj, nhalo);
-    __syncthreads();  // vmcnt(0) (this wave's DMA and records; the previous item's stores as well) + barrier: image complete
+    GCL_AGG_STAMP(1)  // DMA issue
+    __syncthreads();  // vmcnt(0) (this wave's DMA, new records; the previous item's stores as well) + barrier: image complete
+    GCL_AGG_STAMP(2)  // landed + barrier
 
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -575,10 +585,17 @@ __global__ __launch_bounds__(256) void agg_halo_loop_kernel(const int32_t* __res
     const unsigned ad = (unsigned)row_bcast<K>(rxb) + lb;           \
     const float wk = __int_as_float(row_bcast<K>(rw));              \
     const v4f v = *(lds4_t)ad;                                      \
-    a0 = mul_then_add(wk, v.x, a0);                                 \
-    a1 = mul_then_add(wk, v.y, a1);                                 \
-    a2 = mul_then_add(wk, v.z, a2);                                 \
-    a3 = mul_then_add(wk, v.w, a3);                                 \
+    if (FMA8) {                                                     \
+      a0 = __fmaf_rn(wk, v.x, a0);                                  \
+      a1 = __fmaf_rn(wk, v.y, a1);                                  \
+      a2 = __fmaf_rn(wk, v.z, a2);                                  \
+      a3 = __fmaf_rn(wk, v.w, a3);                                  \
+    } else {                                                        \
+      a0 = mul_then_add(wk, v.x, a0);                               \
+      a1 = mul_then_add(wk, v.y, a1);                               \
+      a2 = mul_then_add(wk, v.z, a2);                               \
+      a3 = mul_then_add(wk, v.w, a3);                               \
+    }                                                               \
   }
 #define GCL_HALO_FMA(K)                                             \
   {                                                                 \
@@ -619,11 +636,27 @@ __global__ __launch_bounds__(256) void agg_halo_loop_kernel(const int32_t* __res
         else *reinterpret_cast<v4f*>(yp) = v;
       }
     }
-    if (!more) break;
-    m = mn;
+    GCL_AGG_STAMP(3)  // sums + store issue
+#ifdef GCL_STAMPS
+    st_acc[5] += 1;
+#endif
+    if (++m >= mend) break;
     __syncthreads();  // every wave is done reading the image
+    GCL_AGG_STAMP(4)  // image free again
   }
+#ifdef GCL_STAMPS
+  if (lane == 0 && (blockIdx.x * NW + wave) < 4096)
+    for (int i = 0; i < 8; ++i) agg_stamps[(blockIdx.x * NW + wave) * 8 + i] = st_acc[i];
+#endif
 }
+
+#ifdef GCL_STAMPS
+extern "C" int gcl_debug_read_agg_stamps(unsigned long long* host_out, int count) {
+  GCL_CHECK_HIP(hipDeviceSynchronize());
+  GCL_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(agg_stamps), sizeof(unsigned long long) * count));
+  return GCL_OK;
+}
+#endif
 
 int agg_env(const char* name, int dflt) {
   const char* e = getenv(name);
@@ -665,7 +698,7 @@ int launch_agg_halo(const AggArgs& ga, const float* h, int64_t ldh, int64_t bsh,
   const int loop = agg_env("GCL_AGG_HALO_LOOP", 1);
   if (loop && lds <= 64 * 1024) {
     // persistent form: blocks per CU by LDS, every block walks its share of the (sample, tile) items of its XCD group
-    const int per_cu = (int)std::min<int64_t>(8, (160 * 1024) / lds);
+    const int per_cu = (int)std::min<int64_t>(agg_env("GCL_AGG_HALO_LNW", 4) == 8 ? 4 : 8, (160 * 1024) / lds);
     const int bpc = agg_env("GCL_AGG_HALO_BPC", per_cu);
     const int J = 32 * bpc;  // blocks per XCD
     dim3 pgrid((unsigned)(gcl::kNumXCD * J)), pblock(256);
@@ -674,13 +707,34 @@ int launch_agg_halo(const AggArgs& ga, const float* h, int64_t ldh, int64_t bsh,
                          ga.rowptr, hl->opos, ga.w, hl->smax, h, ldh, bsh, bias, y, ldy, bsy, n, B, F, hl->ntiles, nt);
       return GCL_OK;
     };
-    const int mp4 = (int)gcl::cdiv((hl->smax - hl->T) / RPW, 4);  // this kernel runs 4 waves per block
-    if (hl->T == 64)
-      mp4 <= 4 ? go(&agg_halo_loop_kernel<LPR, 64, 4>) : mp4 <= 8 ? go(&agg_halo_loop_kernel<LPR, 64, 8>)
-          : mp4 <= 16 ? go(&agg_halo_loop_kernel<LPR, 64, 16>) : go(&agg_halo_loop_kernel<LPR, 64, 32>);
-    else
-      mp4 <= 4 ? go(&agg_halo_loop_kernel<LPR, 32, 4>) : mp4 <= 8 ? go(&agg_halo_loop_kernel<LPR, 32, 8>)
-          : mp4 <= 16 ? go(&agg_halo_loop_kernel<LPR, 32, 16>) : go(&agg_halo_loop_kernel<LPR, 32, 32>);
+    const int lnw = (agg_env("GCL_AGG_HALO_LNW", 4) == 8 && hl->T / 8 >= RPW) ? 8 : 4;  // waves per block
+    const int fma8 = agg_env("GCL_AGG_HALO_FMA", 0);
+    const int mpw = (int)gcl::cdiv((hl->smax - hl->T) / RPW, lnw);
+    pblock = dim3(64 * lnw);
+#define GCL_LOOP_L(T_, MP_, NW_, F_)                                 \
+  do {                                                               \
+    if constexpr ((T_) / (NW_) >= RPW) go(&agg_halo_loop_kernel<LPR, T_, MP_, NW_, F_>); \
+  } while (0)
+#define GCL_LOOP_M(T_, NW_, F_)                                      \
+  do {                                                               \
+    if (mpw <= 2) GCL_LOOP_L(T_, 2, NW_, F_);                        \
+    else if (mpw <= 4) GCL_LOOP_L(T_, 4, NW_, F_);                   \
+    else if (mpw <= 8) GCL_LOOP_L(T_, 8, NW_, F_);                   \
+    else if (mpw <= 16) GCL_LOOP_L(T_, 16, NW_, F_);                 \
+    else GCL_LOOP_L(T_, 32, NW_, F_);                                \
+  } while (0)
+#define GCL_LOOP_T(T_)                                               \
+  do {                                                               \
+    if (lnw == 8 && fma8) GCL_LOOP_M(T_, 8, true);                   \
+    else if (lnw == 8) GCL_LOOP_M(T_, 8, false);                     \
+    else if (fma8) GCL_LOOP_M(T_, 4, true);                          \
+    else GCL_LOOP_M(T_, 4, false);                                   \
+  } while (0)
+    if (hl->T == 64) GCL_LOOP_T(64);
+    else GCL_LOOP_T(32);
+#undef GCL_LOOP_T
+#undef GCL_LOOP_M
+#undef GCL_LOOP_L
     GCL_CHECK_LAUNCH();
     return GCL_OK;
   }

@@ -358,6 +358,10 @@ class _Deferred:
     def __init__(self):
         self.active = False
         self.jobs, self.dests, self.pool, self.used = [], set(), [], 0
+        # the queued job only carries raw pointers: the destination (and slope-gradient) tensors are held here until
+        # the flush, so a temporary one (the gradient slot of a frozen parameter) cannot be freed and its block handed
+        # to another tensor before the final pass writes it
+        self.keep = []
 
     def ws(self, nbytes, device):
         if self.used == len(self.pool):
@@ -380,15 +384,19 @@ def defer_begin():
     _deferred.active = True
 
 
-def defer_flush(close: bool = True):
-    """Run the pending final passes (gcl_reduce_jobs) on the current stream."""
+def defer_flush(close: bool = True, drop: bool = False):
+    """Run the pending final passes (gcl_reduce_jobs) on the current stream.  `drop` discards them instead (the
+    backward that queued them failed).  The queue is emptied whatever happens, so a failed launch cannot leave
+    later, unrelated backward calls queueing into a list nobody flushes."""
     d = _deferred
-    if d.jobs:
-        arr = (ReduceJob * len(d.jobs))(*d.jobs)
-        _check(lib().gcl_reduce_jobs(C.cast(arr, C.c_void_p), len(d.jobs), _stream()))
-    d.jobs, d.dests, d.used = [], set(), 0
-    if close:
-        d.active = False
+    try:
+        if d.jobs and not drop:
+            arr = (ReduceJob * len(d.jobs))(*d.jobs)
+            _check(lib().gcl_reduce_jobs(C.cast(arr, C.c_void_p), len(d.jobs), _stream()))
+    finally:
+        d.jobs, d.dests, d.used, d.keep = [], set(), 0, []
+        if close:
+            d.active = False
 
 
 def linear_bwd_all(dy, W, x, in_slope, d_in_slope, dW, db, colsum_dx, acc_dW: bool, acc_db=None, acc_colsum=None,
@@ -429,6 +437,7 @@ def linear_bwd_all(dy, W, x, in_slope, d_in_slope, dW, db, colsum_dx, acc_dW: bo
         if job.nparts > 0:
             d.jobs.append(job)
             d.dests |= dests
+            d.keep.append((dW, db, colsum_dx, d_in_slope, ws))
         else:
             d.used -= 1  # reduced on the spot: the workspace slot is free again
         return dx

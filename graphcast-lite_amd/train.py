@@ -427,9 +427,12 @@ class TrainStep:
             hip.defer_begin()
         try:
             loss.backward()
-        finally:
+        except BaseException:
             if defer:
-                hip.defer_flush()
+                hip.defer_flush(drop=True)  # a failed backward: forget what it queued, launch nothing
+            raise
+        if defer:
+            hip.defer_flush()
         return loss.detach()
 
     def _finish(self):

@@ -15,12 +15,12 @@ DEV = "cuda:0"
 
 
 def rel(a, b):
-    """max(Frobenius relative error, half the element-wise max|diff| / max|ref|): every `rel(..) < tol`
+    """max(Frobenius relative error, element-wise max|diff| / max|ref|): every `rel(..) < tol`
     below therefore bounds BOTH the norm-wise and the worst single element (one bad element in 10^6 fails)."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     fro = ((a - b).norm() / (b.norm() + 1e-30)).item()
     mx = ((a - b).abs().max() / (b.abs().max() + 1e-30)).item() if b.numel() else 0.0
-    return max(fro, 0.5 * mx)
+    return max(fro, mx)
 
 
 def arbitrated_grad_check(m, o, loss_fn64, tag):
@@ -65,7 +65,7 @@ def data(cfg, G, B, seed=1234):
 
 @pytest.mark.parametrize("name,levels,B", [("baseline", [1, 2], 2), ("baseline", [3, 5], 3), ("baseline", [3, 5], 64),
                                            ("attention", [1, 2], 2),
-                                           ("attention", [3, 5], 2), ("attention_h4", [1, 2], 2),
+                                           ("attention", [3, 5], 2), ("attention", [3, 5], 64), ("attention_h4", [1, 2], 2),
                                            ("sparse_attention", [1, 2], 2), ("wb2_512x256_19f_ar", [1, 2], 2),
                                            ("region_krsk_cds_19f", [1, 2], 2), ("region_krsk_cds_19f", [2, 3], 1),
                                            ("wb2_512x256_19f_ar_v2", [1, 2], 1),
@@ -235,6 +235,42 @@ def test_train_step_matches_torch_adam_on_oracle():
     od = dict(o.named_parameters())
     for n_, p in m.named_parameters():
         assert rel(p, od[n_]) < 1e-4, n_
+
+
+def test_train_step_with_frozen_processor_and_rollout(monkeypatch):
+    """`freeze_processor_epochs` (src/main.py:197-203) under TrainStep's deferred final passes and a 3-step
+    autoregressive rollout: the gradient slots of frozen parameters are temporaries, which the queued passes write
+    AFTER the autograd Function that made them has returned - they must be kept alive until the flush.  The
+    deferred step must follow the step with immediate reductions parameter for parameter, frozen ones untouched."""
+    from graphcast_lite_amd import train as TR
+
+    cfg, m1, _ = make_pair("baseline", [1, 2])
+    _, m2, _ = make_pair("baseline", [1, 2])
+    for m in (m1, m2):
+        for p in m.processor.parameters():
+            p.requires_grad = False
+    G, F = m1._num_grid_nodes, cfg.data.num_features_used
+    X, _ = data(cfg, G, 3)
+    g = torch.Generator().manual_seed(9)
+    y = torch.randn(3, G, 3 * F, generator=g)
+    lw = TR.get_lat_weights(32, 64, DEV)
+    before = {n_: p.detach().clone() for n_, p in m1.processor.named_parameters()}
+    s1 = TR.TrainStep(m1, lr=1e-3, lat_weights=lw, ar_steps=3, use_graph=False)
+    monkeypatch.setattr(TR, "_DEFER_REDUCTIONS", False)
+    s2 = TR.TrainStep(m2, lr=1e-3, lat_weights=lw, ar_steps=3, use_graph=False)
+    for i in range(3):
+        monkeypatch.setattr(TR, "_DEFER_REDUCTIONS", True)
+        l1 = s1(X.to(DEV) * (1 + 0.1 * i), y.to(DEV))
+        junk = [torch.full((64, 64), float(i), device=DEV) for _ in range(8)]  # would reuse a freed gradient slot
+        monkeypatch.setattr(TR, "_DEFER_REDUCTIONS", False)
+        l2 = s2(X.to(DEV) * (1 + 0.1 * i), y.to(DEV))
+        assert rel(l1, l2) < 1e-6
+        assert all(bool((j == float(i)).all()) for j in junk), "a queued final pass wrote into a tensor that is not its own"
+    p2 = dict(m2.named_parameters())
+    for n_, p in m1.named_parameters():
+        assert rel(p, p2[n_]) < 1e-6, n_
+    for n_, p in m1.processor.named_parameters():
+        assert torch.equal(p, before[n_]), f"frozen parameter {n_} moved"
 
 
 def test_graph_captured_step_equals_eager():

@@ -14,12 +14,12 @@ TOL = 1e-5
 
 
 def rel(a, b):
-    """max(Frobenius relative error, half the element-wise max|diff| / max|ref|): every `rel(..) < tol`
+    """max(Frobenius relative error, element-wise max|diff| / max|ref|): every `rel(..) < tol`
     below bounds BOTH the norm-wise error and the worst single element."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     fro = ((a - b).norm() / (b.norm() + 1e-30)).item()
     mx = ((a - b).abs().max() / (b.abs().max() + 1e-30)).item() if b.numel() else 0.0
-    return max(fro, 0.5 * mx)
+    return max(fro, mx)
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -472,7 +472,7 @@ def test_colsum(hip, rows, F):
     assert rel(out, x.sum(0) + 1) < TOL
 
 
-@pytest.mark.parametrize("levels,H,C,B", [([1, 2], 1, 64, 3), ([3, 5], 1, 64, 2), ([1, 2], 4, 64, 2), ([0], 2, 16, 1),
+@pytest.mark.parametrize("levels,H,C,B", [([1, 2], 1, 64, 3), ([3, 5], 1, 64, 2), ([3, 5], 1, 64, 9), ([1, 2], 4, 64, 2), ([0], 2, 16, 1),
                                           ([1, 2], 1, 128, 2),
                                           # head counts the reference reports (README.md:148-150): 8 and 33 heads at C = 64
                                           # run as chunks of <= 4 heads; 3 and 6 heads exercise the uneven chunking

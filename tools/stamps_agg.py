@@ -1,6 +1,6 @@
 """Diagnostic: where does a wave of the pipelined source-tile aggregation spend its cycles?  Needs the stamped build:
     make -C graphcast-lite_amd/csrc STAMPS=1 && GCL_LIB=graphcast-lite_amd/libgcl_hip_stamps.so python tools/stamps_agg.py
-Prints median cycles per tile for: barrier, DMA issue, sums + store issue, wait for the next tile."""
+Prints median cycles per (tile, sample) item and phase of agg_halo_loop_kernel (GCL_AGG_HALO_LOOP=0: of agg_halo_kernel)."""
 import ctypes as C
 import os
 import sys
@@ -33,7 +33,7 @@ torch.cuda.synchronize()
 buf = np.zeros(8 * 4096, dtype=np.uint64)
 assert L.gcl_debug_read_agg_stamps(buf.ctypes.data, buf.size) == 0
 st = buf.reshape(-1, 8).astype(np.float64)
-if os.environ.get("GCL_AGG_HALO_PIPE", "1") == "0":
+if os.environ.get("GCL_AGG_HALO_LOOP", "1") == "0":
     # one tile per block: entry..own DMAs | list wait + halo DMAs + records | landed + barrier | sums + stores
     st = st[st[:, :4].sum(axis=1) > 0]
     for i, nm in enumerate(["entry + own DMA issue", "list wait + halo DMA + records", "landed + barrier", "sums + store issue"]):
@@ -41,11 +41,11 @@ if os.environ.get("GCL_AGG_HALO_PIPE", "1") == "0":
     print(f"  total median {np.median(st[:, :4].sum(axis=1)):.0f} cycles per wave")
     sys.exit(0)
 st = st[st[:, 5] > 0]
-names = ["prologue", "barrier", "dma issue", "sums+stores", "wait next"]
-tiles = st[:, 5] + 1
+names = ["new tile", "dma issue", "landed+barrier", "sums+stores", "free barrier"]
+tiles = st[:, 5]
 print(f"waves {len(st)}, tiles per wave median {np.median(tiles):.0f}")
 for i, nm in enumerate(names):
-    per = st[:, i] / (tiles if i else 1)
-    print(f"  {nm:12s} median {np.median(per):8.0f} cycles per {'tile' if i else 'wave'}  (p10 {np.percentile(per, 10):.0f}, p90 {np.percentile(per, 90):.0f})")
+    per = st[:, i] / tiles
+    print(f"  {nm:14s} median {np.median(per):8.0f} cycles per item  (p10 {np.percentile(per, 10):.0f}, p90 {np.percentile(per, 90):.0f})")
 tot = st[:, :5].sum(axis=1)
 print(f"  total per wave median {np.median(tot):.0f} cycles; per tile {np.median(tot / tiles):.0f}")
