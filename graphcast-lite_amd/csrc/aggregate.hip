@@ -259,19 +259,28 @@ __global__ __launch_bounds__(256) void agg_heavy_kernel(const int32_t* __restric
 // ---------------------------------------------------------------------------------------------------------
 // Source-tile ("halo") aggregation.  agg_kernel gathers every edge's source row through the L1/TA path: B*E' rows
 // per launch, ~3.4x the algorithmic bytes on the mesh graph, and that path (not HBM) bounds it.  Here a block owns
-// a tile of T consecutive rows: it stages the tile's DISTINCT source rows once (LDS-DMA row gather, the list is
-// precomputed per graph: gcl_halo) and forms every sum from LDS, so the vector-memory path carries each source
-// once per tile instead of once per edge.  With tiles that share sources well (mesh nodes numbered by recursive
-// coordinate bisection: 1.7 source rows per destination row at T = 64 instead of 7.4 edge reads) HBM is the bound.
+// a tile of T consecutive rows at a time: it stages the tile's own rows and the DISTINCT source rows outside the
+// tile (its halo; the list is precomputed per graph: gcl_halo) once by LDS-DMA and forms every sum from LDS, so the
+// vector-memory path carries each source once per tile instead of once per edge.  With tiles that share sources well
+// (mesh nodes numbered by recursive coordinate bisection: 1.7 staged rows per destination row at T = 64 instead of
+// 7.4 edge reads) the kernel runs at 0.74 of the 8 TB/s HBM roofline instead of 0.50-0.58.
 //
-// Block = 4 waves.  {tile count} -> {list entries of this wave's DMA pieces, edge records of this wave's rows}
-// -> LDS-DMA of the source rows -> barrier -> sums: a row is owned by LPR lanes (4 channels each), its first 16
-// edge records {image position, weight} sit one per lane and are broadcast with DPP row_newbcast (no LDS traffic),
-// the source values come from ds_read_b128 (conflict-free for any row set: 16 lanes x 16 B span all 64 banks).
-// Slots 0..7 are read unconditionally (padding points at a zero row with weight 0), slots 8..15 when some row of
-// the wave-instruction has that many edges, rows with more than 16 edges finish from the CSR arrays.
-// Arithmetic is that of agg_kernel<.., EW = 8>, bit for bit: product and sum rounded separately for the first
-// eight edges of a row (PyG's multiply, then scatter_add), fused multiply-add for the rest, in CSR order.
+// Sums: a row is owned by LPR lanes (4 channels each), its first 16 edge records {image position, weight} sit one per
+// lane and are broadcast with DPP row_newbcast (no LDS traffic; broadcast + address is ONE v_add_u32_dpp), the source
+// values come from ds_read_b128 (conflict-free for any row set: 16 lanes x 16 B span all 64 banks).  Slots 0..7 are
+// read unconditionally (padding points at a zero row with weight 0), slots 8..15 when some row of the wave-instruction
+// has that many edges, rows with more than 16 edges finish from the CSR arrays.
+// Arithmetic is that of agg_kernel<.., EW = 8>, bit for bit: product and sum rounded separately for the first eight
+// edges of a row (PyG's multiply, then scatter_add), fused multiply-add for the rest, in CSR order.
+//
+// What was tried on the way (profiles/r03_halo_*.txt, tools/probes/tile_copy_probe.hip): one tile per block (64 us:
+// half of a block's life passes before its last load is issued), that form with 8 / 16 waves per tile (71 / 88 us),
+// two images per block with the next tile's DMA under this tile's sums (62 us at two blocks per CU: sums at two waves
+// per SIMD run at single-wave issue rate), a loader wave + summing waves (69 us: one wave issues 30 DMAs per tile one
+// after the other), fused multiply-add for all slots (no change: the sums are not bound by the FP pipe).  A probe with
+// this structure but no lists, synthetic records and exactly 8 slots copies the same bytes in 50 us; re-reading a
+// tile's 128-byte-per-row records for every sample costs 17 us of that difference and the scalar-loaded list 6 us -
+// which is why a block here keeps both in registers across the samples of its XCD group.
 // ---------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) const void* gcl_gptr_t;
 typedef __attribute__((address_space(3))) void* gcl_lptr_t;
@@ -300,168 +309,6 @@ __device__ unsigned long long agg_stamps[8 * 4096];  // diagnostic builds only (
 #define GCL_AGG_STAMP(i)
 #endif
 
-template <int LPR, int T, int MAXPW, int NW>
-__global__ __launch_bounds__(64 * NW) void agg_halo_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ cnt,
-                                                       const int2* __restrict__ rec, const int32_t* __restrict__ rowptr,
-                                                       const int32_t* __restrict__ opos, const float* __restrict__ w,
-                                                       int32_t smax, const float* __restrict__ H, int64_t ldh,
-                                                       int64_t bsh, const float* __restrict__ bias,
-                                                       float* __restrict__ Y, int64_t ldy, int64_t bsy, int32_t n,
-                                                       int32_t B, int32_t F, int32_t ntiles, int32_t xcd_map,
-                                                       int32_t nt_store, int32_t skew) {
-  extern __shared__ float4 img[];  // [(smax + 1) * LPR]: the tile's own rows, its halo rows, then the zero row
-  constexpr int RPW = 64 / LPR;    // rows per wave-instruction
-  constexpr int NIT = T / NW / RPW; // wave-instructions of rows per wave (NW waves per block)
-#ifdef GCL_STAMPS
-  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
-#endif
-  const int bid = blockIdx.x;
-  int b, tile;
-  if (xcd_map) {
-    const int xcd = bid & (gcl::kNumXCD - 1);
-    const int slot = bid >> 3;
-    b = xcd + gcl::kNumXCD * (slot / ntiles);
-    tile = slot % ntiles;
-  } else {
-    b = bid / ntiles;
-    tile = bid % ntiles;
-  }
-  if (b >= B) return;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform (scalar loads and branches below)
-  const int sub = lane / LPR;
-  const int l = lane % LPR;
-  const int c0 = l * 4;
-  const bool cactive = c0 < F;
-  const int cc = cactive ? c0 : 0;  // inactive channel lanes stage channel 0 again (never stored)
-  // one sample's rows are addressed by 32-bit byte offsets from a scalar base (the launcher checks n * ldh * 4 < 2^31
-  // and ldh * 4 < 2^24): one v_mad_u32_u24 per row instead of a 64-bit multiply
-  const char* __restrict__ Hc = reinterpret_cast<const char*>(H + (int64_t)b * bsh);
-  const unsigned ldb = (unsigned)ldh * 4u, cb = (unsigned)cc * 4u;
-  float* __restrict__ Yb = Y + (int64_t)b * bsy;
-  const int hstride = smax - T;
-
-  // halo list entries of this wave's pieces: wave-uniform addresses -> scalar loads (lgkmcnt), so they neither wait
-  // for nor are waited for by the vector-memory counter the DMAs sit on.  Piece p = image rows [T + p*RPW, ..+RPW).
-  const int nhalo = cnt[tile] / RPW;
-  const int32_t* __restrict__ tl = list + (int64_t)tile * hstride;
-  int jj[MAXPW];
-#pragma unroll
-  for (int q = 0; q < MAXPW; ++q) {
-    const int e0 = min((wave + NW * q) * RPW, hstride - RPW);  // clamped: every entry of a tile's list is a valid row
-    int j = tl[e0];
-#pragma unroll
-    for (int r = 1; r < RPW; ++r) {
-      const int jr = tl[e0 + r];
-      j = sub == r ? jr : j;
-    }
-    jj[q] = j;
-  }
-  // (an LDS store issued while a DMA is in flight would make hipcc drain the DMAs first: zero row before them)
-  if (threadIdx.x < LPR) img[smax * LPR + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
-  // own rows: no list, no dependency - in flight while the list arrives
-  const int row0 = tile * T + wave * (T / NW) + sub;
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int row = row0 + it * RPW;
-    const char* src = Hc + (__umul24(row < n ? row : n - 1, ldb) + cb);
-    __builtin_amdgcn_global_load_lds((gcl_gptr_t)src, (gcl_lptr_t)(img + (wave * (T / NW) + it * RPW) * LPR), 16, 0, 0);
-  }
-  GCL_AGG_STAMP(0)  // entry .. own DMAs issued
-  if (skew) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // experiment: halo rows only after the own rows landed
-#pragma unroll
-  for (int q = 0; q < MAXPW; ++q) {
-    const int p = wave + NW * q;
-    if (p < nhalo) {
-      const char* src = Hc + (__umul24(jj[q], ldb) + cb);
-      __builtin_amdgcn_global_load_lds((gcl_gptr_t)src, (gcl_lptr_t)(img + (T + p * RPW) * LPR), 16, 0, 0);
-    }
-  }
-  // edge records of this wave's rows (used after the barrier)
-  int2 rc[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int row = row0 + it * RPW;
-    rc[it] = rec[(int64_t)(row < n ? row : n - 1) * gcl::kHaloRec + (l & (gcl::kHaloRec - 1))];
-  }
-  GCL_AGG_STAMP(1)  // list wait + halo DMAs + record loads issued
-  float bz0 = 0.f, bz1 = 0.f, bz2 = 0.f, bz3 = 0.f;
-  if (bias && cactive) {
-    const float4 bv = *reinterpret_cast<const float4*>(bias + c0);  // F % 4 == 0 on this path
-    bz0 = bv.x; bz1 = bv.y; bz2 = bv.z; bz3 = bv.w;
-  }
-  __syncthreads();  // waits for the wave's DMA (vmcnt(0)) and for everyone else's
-  GCL_AGG_STAMP(2)  // landed + barrier
-
-  // LDS byte address of this lane's 16 bytes of image row 0, as an integer: `row_bcast(offset) + lb` is then a plain
-  // two-operand add, which hipcc folds into ONE v_add_u32_dpp (broadcast + address) per edge
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  typedef __attribute__((address_space(3))) const v4f* lds4_t;
-  const unsigned lb = (unsigned)(size_t)((gcl_lptr_t)img) + (unsigned)l * 16u;
-  constexpr int SH = LPR == 16 ? 8 : LPR == 32 ? 9 : 10;  // log2 of the bytes of an image row
-  const int zrow = smax << SH;
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int row = row0 + it * RPW;
-    const int rx = rc[it].x, rw = rc[it].y;
-    const int rxb = (rx & gcl::kHaloPosMask) << SH;  // byte offset of the source's image row (slot 15: flags stripped)
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#define GCL_HALO_MULADD(K)                                          \
-  {                                                                 \
-    const unsigned ad = (unsigned)row_bcast<K>(rxb) + lb;           \
-    const float wk = __int_as_float(row_bcast<K>(rw));              \
-    const v4f v = *(lds4_t)ad;                                      \
-    a0 = mul_then_add(wk, v.x, a0);                                 \
-    a1 = mul_then_add(wk, v.y, a1);                                 \
-    a2 = mul_then_add(wk, v.z, a2);                                 \
-    a3 = mul_then_add(wk, v.w, a3);                                 \
-  }
-#define GCL_HALO_FMA(K)                                             \
-  {                                                                 \
-    const unsigned ad = (unsigned)row_bcast<K>(rxb) + lb;           \
-    const float wk = __int_as_float(row_bcast<K>(rw));              \
-    const v4f v = *(lds4_t)ad;                                      \
-    a0 = __fmaf_rn(wk, v.x, a0);                                    \
-    a1 = __fmaf_rn(wk, v.y, a1);                                    \
-    a2 = __fmaf_rn(wk, v.z, a2);                                    \
-    a3 = __fmaf_rn(wk, v.w, a3);                                    \
-  }
-    GCL_HALO_MULADD(0) GCL_HALO_MULADD(1) GCL_HALO_MULADD(2) GCL_HALO_MULADD(3)
-    GCL_HALO_MULADD(4) GCL_HALO_MULADD(5) GCL_HALO_MULADD(6) GCL_HALO_MULADD(7)
-    const int last = row_bcast<15>(rx);  // slot 15 carries the row flags
-    if (__any(row_bcast<8>(rxb) != zrow)) {  // wave-uniform: some row here has more than 8 edges
-      GCL_HALO_FMA(8) GCL_HALO_FMA(9) GCL_HALO_FMA(10) GCL_HALO_FMA(11)
-      GCL_HALO_FMA(12) GCL_HALO_FMA(13) GCL_HALO_FMA(14) GCL_HALO_FMA(15)
-      if (__any((last & gcl::kHaloMore) != 0)) {  // more than 16 edges: the rest from the CSR arrays
-        const int rcl = row < n ? row : n - 1;
-        const int end = (last & gcl::kHaloMore) ? rowptr[rcl + 1] : 0;
-        for (int e = rowptr[rcl] + gcl::kHaloRec; e < end; ++e) {
-          const float wk = w[e];
-          const v4f v = *(lds4_t)(((unsigned)opos[e] << SH) + lb);
-          a0 = __fmaf_rn(wk, v.x, a0);
-          a1 = __fmaf_rn(wk, v.y, a1);
-          a2 = __fmaf_rn(wk, v.z, a2);
-          a3 = __fmaf_rn(wk, v.w, a3);
-        }
-      }
-    }
-#undef GCL_HALO_MULADD
-#undef GCL_HALO_FMA
-    if (row < n && cactive && !(last & gcl::kHaloSkip)) {
-      a0 += bz0; a1 += bz1; a2 += bz2; a3 += bz3;
-      float* __restrict__ yp = Yb + (int64_t)row * ldy + c0;
-      v4f v = {a0, a1, a2, a3};
-      if (nt_store) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(yp));
-      else *reinterpret_cast<v4f*>(yp) = v;
-    }
-  }
-  GCL_AGG_STAMP(3)  // sums + stores issued
-#ifdef GCL_STAMPS
-  if (lane == 0 && (blockIdx.x * NW + wave) < 4096)
-    for (int i = 0; i < 8; ++i) agg_stamps[(blockIdx.x * NW + wave) * 8 + i] = st_acc[i];
-#endif
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // The same aggregation with PERSISTENT blocks.  Stamps of agg_halo_kernel (tools/stamps_agg.py) put half of a
 // block's life before its last load is issued - kernel arguments, block -> (sample, tile) arithmetic, the tile's
@@ -474,8 +321,8 @@ __global__ __launch_bounds__(64 * NW) void agg_halo_kernel(const int32_t* __rest
 // stores of one item are still in flight while the loads of the next are issued.  One image per block, two
 // barriers per item (loaded / free again).
 // ---------------------------------------------------------------------------------------------------------
-template <int LPR, int T, int MAXPW, int NW, bool FMA8>
-__global__ __launch_bounds__(64 * NW) void agg_halo_loop_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ cnt,
+template <int LPR, int T, int MAXPW>
+__global__ __launch_bounds__(256) void agg_halo_loop_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ cnt,
                                                             const int2* __restrict__ rec, const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ opos, const float* __restrict__ w,
                                                             int32_t smax, const float* __restrict__ H, int64_t ldh,
@@ -484,7 +331,8 @@ __global__ __launch_bounds__(64 * NW) void agg_halo_loop_kernel(const int32_t* _
                                                             int32_t B, int32_t F, int32_t ntiles, int32_t nt_store) {
   extern __shared__ float4 img[];  // (smax + 1) * LPR float4: own rows, halo rows, zero row
   constexpr int RPW = 64 / LPR;
-  constexpr int NIT = T / NW / RPW;
+  constexpr int NW = 4;              // waves per block
+  constexpr int NIT = T / NW / RPW;  // row groups (wave-instructions) per wave and tile
   constexpr int SH = LPR == 16 ? 8 : LPR == 32 ? 9 : 10;  // log2 of the bytes of an image row
   typedef float v4f __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) const v4f* lds4_t;
@@ -542,14 +390,10 @@ __global__ __launch_bounds__(64 * NW) void agg_halo_loop_kernel(const int32_t* _
     const int tnew = m / nsamp;
     const int s = m - tnew * nsamp;
     const int b = xcd + gcl::kNumXCD * s;
-    if (tnew != tile) {  // wave-uniform: a new tile - its list entries and edge records serve all samples of the group
+    const bool newtile = tnew != tile;  // wave-uniform: its list entries and edge records serve all samples of the group
+    if (newtile) {
       tile = tnew;
       fetch_list(tile, jj, nhalo);
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int row = tile * T + wave * (T / NW) + sub + it * RPW;
-        rc[it] = rec[(int64_t)(row < n ? row : n - 1) * gcl::kHaloRec + (l & (gcl::kHaloRec - 1))];
-      }
     }
     GCL_AGG_STAMP(0)  // new tile: list + records
     const char* Hc = reinterpret_cast<const char*>(H + (int64_t)b * bsh);
@@ -570,6 +414,13 @@ __global__ __launch_bounds__(64 * NW) void agg_halo_loop_kernel(const int32_t* _
         __builtin_amdgcn_global_load_lds((gcl_gptr_t)src, (gcl_lptr_t)(img + (T + p * RPW) * LPR), 16, 0, 0);
       }
     }
+    if (newtile) {  // records AFTER the DMAs: hipcc waits for them where this block ends, i.e. together with the tile
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = row0 + it * RPW;
+        rc[it] = rec[(int64_t)(row < n ? row : n - 1) * gcl::kHaloRec + (l & (gcl::kHaloRec - 1))];
+      }
+    }
     GCL_AGG_STAMP(1)  // DMA issue
     __syncthreads();  // vmcnt(0) (this wave's DMA, new records; the previous item's stores as well) + barrier: image complete
     GCL_AGG_STAMP(2)  // landed + barrier
@@ -585,17 +436,10 @@ __global__ __launch_bounds__(64 * NW) void agg_halo_loop_kernel(const int32_t* _
     const unsigned ad = (unsigned)row_bcast<K>(rxb) + lb;           \
     const float wk = __int_as_float(row_bcast<K>(rw));              \
     const v4f v = *(lds4_t)ad;                                      \
-    if (FMA8) {                                                     \
-      a0 = __fmaf_rn(wk, v.x, a0);                                  \
-      a1 = __fmaf_rn(wk, v.y, a1);                                  \
-      a2 = __fmaf_rn(wk, v.z, a2);                                  \
-      a3 = __fmaf_rn(wk, v.w, a3);                                  \
-    } else {                                                        \
-      a0 = mul_then_add(wk, v.x, a0);                               \
-      a1 = mul_then_add(wk, v.y, a1);                               \
-      a2 = mul_then_add(wk, v.z, a2);                               \
-      a3 = mul_then_add(wk, v.w, a3);                               \
-    }                                                               \
+    a0 = mul_then_add(wk, v.x, a0);                                 \
+    a1 = mul_then_add(wk, v.y, a1);                                 \
+    a2 = mul_then_add(wk, v.z, a2);                                 \
+    a3 = mul_then_add(wk, v.w, a3);                                 \
   }
 #define GCL_HALO_FMA(K)                                             \
   {                                                                 \
@@ -675,7 +519,8 @@ template <int LPR>
 int launch_agg_halo(const AggArgs& ga, const float* h, int64_t ldh, int64_t bsh, const float* bias, float* y,
                     int64_t ldy, int64_t bsy, int32_t n, int32_t B, int32_t F, hipStream_t st) {
   const int enabled = agg_env("GCL_AGG_HALO", 1);  // read per call: the parity tests switch it to compare the two kernels
-  static const int force_t = agg_env("GCL_AGG_HALO_T", 0);
+  static const int force_t = agg_env("GCL_AGG_HALO_T", 0);    // tuning: tile height
+  static const int bpc_env = agg_env("GCL_AGG_HALO_BPC", 0);  // tuning: blocks per CU
   static const int nt = agg_env("GCL_AGG_NT", 1);
   if (!enabled || ga.ell_width != 8) return -1;  // the arithmetic below is that of agg_kernel<.., EW = 8>
   if ((int64_t)n * ldh * 4 >= (int64_t)1 << 31 || ldh * 4 >= (int64_t)1 << 24 || n >= 1 << 24) return -1;  // 32-bit row offsets
@@ -684,94 +529,33 @@ int launch_agg_halo(const AggArgs& ga, const float* h, int64_t ldh, int64_t bsh,
   for (int t = 0; t < 2; ++t) {
     const gcl_halo& c = ga.halo[t];
     if (c.T == 0 || (force_t && c.T != force_t)) continue;
-    const int64_t lds = (int64_t)(c.smax + 1) * LPR * 16;
-    if (lds > (c.T == 64 ? 40 : 53) * 1024 || gcl::cdiv((c.smax - c.T) / RPW, 4) > 32) continue;
+    const int64_t bytes = (int64_t)(c.smax + 1) * LPR * 16;
+    if (bytes > 80 * 1024 || gcl::cdiv((c.smax - c.T) / RPW, 4) > 32) continue;  // at least two blocks per CU
     hl = &c;
     break;
   }
   if (!hl) return -1;
   const int64_t lds = (int64_t)(hl->smax + 1) * LPR * 16;
-  int nw = agg_env("GCL_AGG_HALO_NW", 8);  // waves per block (tile): more waves = shorter block life at the same LDS
-  nw = (nw == 16 && hl->T / 16 >= RPW) ? 16 : (nw >= 8 && hl->T / 8 >= RPW) ? 8 : 4;
-  const int maxpw = (int)gcl::cdiv((hl->smax - hl->T) / RPW, nw);
-  const int skew = agg_env("GCL_AGG_HALO_SKEW", 0);
-  const int loop = agg_env("GCL_AGG_HALO_LOOP", 1);
-  if (loop && lds <= 64 * 1024) {
-    // persistent form: blocks per CU by LDS, every block walks its share of the (sample, tile) items of its XCD group
-    const int per_cu = (int)std::min<int64_t>(agg_env("GCL_AGG_HALO_LNW", 4) == 8 ? 4 : 8, (160 * 1024) / lds);
-    const int bpc = agg_env("GCL_AGG_HALO_BPC", per_cu);
-    const int J = 32 * bpc;  // blocks per XCD
-    dim3 pgrid((unsigned)(gcl::kNumXCD * J)), pblock(256);
-    auto go = [&](auto kern) -> int {
-      hipLaunchKernelGGL(kern, pgrid, pblock, (size_t)lds, st, hl->list, hl->cnt, reinterpret_cast<const int2*>(hl->rec),
-                         ga.rowptr, hl->opos, ga.w, hl->smax, h, ldh, bsh, bias, y, ldy, bsy, n, B, F, hl->ntiles, nt);
-      return GCL_OK;
-    };
-    const int lnw = (agg_env("GCL_AGG_HALO_LNW", 4) == 8 && hl->T / 8 >= RPW) ? 8 : 4;  // waves per block
-    const int fma8 = agg_env("GCL_AGG_HALO_FMA", 0);
-    const int mpw = (int)gcl::cdiv((hl->smax - hl->T) / RPW, lnw);
-    pblock = dim3(64 * lnw);
-#define GCL_LOOP_L(T_, MP_, NW_, F_)                                 \
-  do {                                                               \
-    if constexpr ((T_) / (NW_) >= RPW) go(&agg_halo_loop_kernel<LPR, T_, MP_, NW_, F_>); \
-  } while (0)
-#define GCL_LOOP_M(T_, NW_, F_)                                      \
-  do {                                                               \
-    if (mpw <= 2) GCL_LOOP_L(T_, 2, NW_, F_);                        \
-    else if (mpw <= 4) GCL_LOOP_L(T_, 4, NW_, F_);                   \
-    else if (mpw <= 8) GCL_LOOP_L(T_, 8, NW_, F_);                   \
-    else if (mpw <= 16) GCL_LOOP_L(T_, 16, NW_, F_);                 \
-    else GCL_LOOP_L(T_, 32, NW_, F_);                                \
-  } while (0)
-#define GCL_LOOP_T(T_)                                               \
-  do {                                                               \
-    if (lnw == 8 && fma8) GCL_LOOP_M(T_, 8, true);                   \
-    else if (lnw == 8) GCL_LOOP_M(T_, 8, false);                     \
-    else if (fma8) GCL_LOOP_M(T_, 4, true);                          \
-    else GCL_LOOP_M(T_, 4, false);                                   \
-  } while (0)
-    if (hl->T == 64) GCL_LOOP_T(64);
-    else GCL_LOOP_T(32);
-#undef GCL_LOOP_T
-#undef GCL_LOOP_M
-#undef GCL_LOOP_L
-    GCL_CHECK_LAUNCH();
+  // persistent blocks, as many per CU as LDS allows; every block walks its share of the (tile, sample) items of its XCD group
+  const int per_cu = (int)std::min<int64_t>(8, (160 * 1024) / lds);
+  const int J = 32 * (bpc_env > 0 ? bpc_env : per_cu);  // blocks per XCD
+  const int mpw = (int)gcl::cdiv((hl->smax - hl->T) / RPW, 4);  // halo pieces per wave of the fullest tile
+  dim3 grid((unsigned)(gcl::kNumXCD * J)), block(256);
+  auto go = [&](auto kern) -> int {
+    const int rc = gcl::ensure_dyn_lds(reinterpret_cast<const void*>(kern), (size_t)lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, grid, block, (size_t)lds, st, hl->list, hl->cnt, reinterpret_cast<const int2*>(hl->rec),
+                       ga.rowptr, hl->opos, ga.w, hl->smax, h, ldh, bsh, bias, y, ldy, bsy, n, B, F, hl->ntiles, nt);
     return GCL_OK;
-  }
-  const int xcd_map = B >= gcl::kNumXCD ? 1 : 0;
-  const int64_t nb = xcd_map ? (int64_t)gcl::kNumXCD * gcl::cdiv(B, gcl::kNumXCD) * hl->ntiles : (int64_t)B * hl->ntiles;
-  GCL_CHECK_ARG(nb < (int64_t)INT32_MAX, "aggregate: grid too large");
-  dim3 grid((unsigned)nb);
-#define GCL_HALO_L(T_, MP_, NW_)                                                                                          \
-  do {                                                                                                                   \
-    if constexpr ((T_) / (NW_) >= RPW)                                                                                   \
-      hipLaunchKernelGGL((agg_halo_kernel<LPR, T_, MP_, NW_>), grid, dim3(64 * NW_), (size_t)lds, st, hl->list, hl->cnt,  \
-                         reinterpret_cast<const int2*>(hl->rec), ga.rowptr, hl->opos, ga.w, hl->smax, h, ldh, bsh, bias,  \
-                         y, ldy, bsy, n, B, F, hl->ntiles, xcd_map, nt, skew);                                            \
-  } while (0)
-#define GCL_HALO_T(T_)                                        \
-  do {                                                        \
-    if (nw == 16) {                                           \
-      if (maxpw <= 1) GCL_HALO_L(T_, 1, 16);                  \
-      else if (maxpw <= 2) GCL_HALO_L(T_, 2, 16);             \
-      else if (maxpw <= 4) GCL_HALO_L(T_, 4, 16);             \
-      else GCL_HALO_L(T_, 8, 16);                             \
-    } else if (nw == 8) {                                     \
-      if (maxpw <= 2) GCL_HALO_L(T_, 2, 8);                   \
-      else if (maxpw <= 4) GCL_HALO_L(T_, 4, 8);              \
-      else if (maxpw <= 8) GCL_HALO_L(T_, 8, 8);              \
-      else GCL_HALO_L(T_, 16, 8);                             \
-    } else {                                                  \
-      if (maxpw <= 4) GCL_HALO_L(T_, 4, 4);                   \
-      else if (maxpw <= 8) GCL_HALO_L(T_, 8, 4);              \
-      else if (maxpw <= 16) GCL_HALO_L(T_, 16, 4);            \
-      else GCL_HALO_L(T_, 32, 4);                             \
-    }                                                         \
-  } while (0)
-  if (hl->T == 64) GCL_HALO_T(64);
-  else GCL_HALO_T(32);
-#undef GCL_HALO_T
-#undef GCL_HALO_L
+  };
+  int rc;
+  if (hl->T == 64)
+    rc = mpw <= 4 ? go(&agg_halo_loop_kernel<LPR, 64, 4>) : mpw <= 8 ? go(&agg_halo_loop_kernel<LPR, 64, 8>)
+       : mpw <= 16 ? go(&agg_halo_loop_kernel<LPR, 64, 16>) : go(&agg_halo_loop_kernel<LPR, 64, 32>);
+  else
+    rc = mpw <= 4 ? go(&agg_halo_loop_kernel<LPR, 32, 4>) : mpw <= 8 ? go(&agg_halo_loop_kernel<LPR, 32, 8>)
+       : mpw <= 16 ? go(&agg_halo_loop_kernel<LPR, 32, 16>) : go(&agg_halo_loop_kernel<LPR, 32, 32>);
+  if (rc) return rc;
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

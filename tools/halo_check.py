@@ -81,7 +81,7 @@ def main():
         same = torch.equal(outs["0"], outs["1"])
         bits = (outs["0"].view(torch.int32) != outs["1"].view(torch.int32)).sum().item()
         print(f"  equal: {same}; elements whose bits differ: {bits}; max |diff| {(outs['0'] - outs['1']).abs().max().item():.3e}")
-        assert (same and bits == 0) or os.environ.get('GCL_AGG_HALO_FMA', '0') != '0'
+        assert same and bits == 0
 
 
 if __name__ == "__main__":

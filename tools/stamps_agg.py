@@ -1,6 +1,6 @@
 """Diagnostic: where does a wave of the pipelined source-tile aggregation spend its cycles?  Needs the stamped build:
     make -C graphcast-lite_amd/csrc STAMPS=1 && GCL_LIB=graphcast-lite_amd/libgcl_hip_stamps.so python tools/stamps_agg.py
-Prints median cycles per (tile, sample) item and phase of agg_halo_loop_kernel (GCL_AGG_HALO_LOOP=0: of agg_halo_kernel)."""
+Prints median cycles per (tile, sample) item and phase of agg_halo_loop_kernel ."""
 import ctypes as C
 import os
 import sys
@@ -33,13 +33,6 @@ torch.cuda.synchronize()
 buf = np.zeros(8 * 4096, dtype=np.uint64)
 assert L.gcl_debug_read_agg_stamps(buf.ctypes.data, buf.size) == 0
 st = buf.reshape(-1, 8).astype(np.float64)
-if os.environ.get("GCL_AGG_HALO_LOOP", "1") == "0":
-    # one tile per block: entry..own DMAs | list wait + halo DMAs + records | landed + barrier | sums + stores
-    st = st[st[:, :4].sum(axis=1) > 0]
-    for i, nm in enumerate(["entry + own DMA issue", "list wait + halo DMA + records", "landed + barrier", "sums + store issue"]):
-        print(f"  {nm:32s} median {np.median(st[:, i]):8.0f} cycles (p10 {np.percentile(st[:, i], 10):.0f}, p90 {np.percentile(st[:, i], 90):.0f})")
-    print(f"  total median {np.median(st[:, :4].sum(axis=1)):.0f} cycles per wave")
-    sys.exit(0)
 st = st[st[:, 5] > 0]
 names = ["new tile", "dma issue", "landed+barrier", "sums+stores", "free barrier"]
 tiles = st[:, 5]
