@@ -529,8 +529,10 @@ def gat_fwd(graph: Graph, h3, att_src, att_dst, bias, H, Cc, need_alpha=True):
     a_d = torch.empty(B, n, H, dtype=torch.float32, device=dev)
     alpha = torch.empty(B, graph.e, H, dtype=torch.float32, device=dev) if need_alpha else None
     y = torch.empty(B, n, Cc, dtype=torch.float32, device=dev)
+    tok = _probe_begin("gat_fwd", graph=graph, B=B, H=H, C=Cc, alpha=need_alpha)
     _check(lib().gcl_gat_fwd(graph.handle, _p(h3), h3.stride(1), h3.stride(0), _p(att_src), _p(att_dst), _p(bias),
                              _p(a_s), _p(a_d), _p(alpha), _p(y), Cc, n * Cc, B, H, Cc, _stream()))
+    _probe_end(tok)
     return y, a_s, a_d, alpha
 
 
@@ -540,9 +542,11 @@ def gat_bwd(graph: Graph, dy3, h3, att_src, att_dst, a_s, a_d, alpha, d_att_src,
     dh = torch.empty(B, n, HC, dtype=torch.float32, device=h3.device)
     nb = lib().gcl_gat_bwd_ws_bytes(graph.e, n, B, H, Cc)
     ws = workspace(nb, h3.device)
+    tok = _probe_begin("gat_bwd", graph=graph, B=B, H=H, C=Cc)
     _check(lib().gcl_gat_bwd(graph.handle, _p(dy3), Cc, n * Cc, _p(h3), h3.stride(1), h3.stride(0), _p(att_src),
                              _p(att_dst), _p(a_s), _p(a_d), _p(alpha), _p(dh), HC, n * HC, _p(d_att_src), _p(d_att_dst),
                              _p(d_bias), 1 if accumulate else 0, B, H, Cc, ws.data_ptr(), ws.numel(), _stream()))
+    _probe_end(tok)
     return dh
 
 

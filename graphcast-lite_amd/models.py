@@ -21,6 +21,7 @@ Compute runs only on a GPU through `libgcl_hip.so`; there is no CPU path in this
 """
 import math
 import os
+import sys
 from collections import OrderedDict
 from typing import Optional, Tuple
 
@@ -169,7 +170,7 @@ class SparseGATConv(GATConv):
         out, alpha_edges, g = self._run(x, edge_index, slope, True)
         alpha = alpha_edges.squeeze()  # [E'] for heads == 1, as in the reference
         if batch_num == 0:
-            print("edge_index", torch.Size([2, g.e]))
+            print("edge_index", torch.Size([2, g.e]), file=sys.stderr)  # the reference prints it too (src/models.py:139): stderr here
             new_ei = hip.gat_prune(g, alpha, float(attention_threshold)).to(x.device)
             new_ei = _broadcast_edges_from_rank0(new_ei)  # C2: every rank keeps rank 0's pruned graph
             mask = alpha >= attention_threshold
@@ -355,7 +356,7 @@ class GraphLayer(nn.Module):
             hidden = list(graph_config.hidden_dims or [])
             if lt == GraphLayerType.SparseGATConv:
                 self.num_heads = graph_config.gat_props.num_heads
-                print(graph_config.layer_type)
+                print(graph_config.layer_type, file=sys.stderr)  # src/models.py:347 prints it; stdout stays clean for callers
                 self.layers.append(SparseGATConv(input_dim, graph_config.output_dim, heads=self.num_heads, concat=False))
             else:
                 if lt == GraphLayerType.GATConv:
@@ -381,7 +382,7 @@ class GraphLayer(nn.Module):
                 hidden_dim=input_dim, num_steps=graph_config.num_message_passing_steps or 4,
                 activation=graph_config.activation or "swish", use_layer_norm=use_ln)
         else:
-            print(graph_config.layer_type)
+            print(graph_config.layer_type, file=sys.stderr)
             raise NotImplementedError(f"Layer type {graph_config.layer_type} not supported.")
 
     @property
@@ -603,6 +604,14 @@ class WeatherPrediction(nn.Module):
             pos[order] = torch.arange(M)
             cached = self._mesh_perm = (order, pos)
         return cached
+
+    def processor_graph(self) -> torch.Tensor:
+        """The edge list the processor is run on: `processing_graph` itself, or (compact pipeline with a GCN
+        processor) the same edges with mesh nodes renamed to tile order.  For callers that look the CSR handle up
+        (bench.py's roofline probe); the model's public attributes keep the reference numbering."""
+        if self._compact_eligible() and self._mesh_order() is not None and not (self.using_sparse_gat or self.using_interaction_net):
+            return self._processing_graph_tiled()
+        return self.processing_graph
 
     def _processing_graph_tiled(self):
         """The processing graph with mesh nodes renamed to tile order (same edge order); rebuilt only when

@@ -19,7 +19,9 @@ from graphcast_lite_amd.experiments import GRID, experiment  # noqa: E402
 from graphcast_lite_amd.models import WeatherPrediction  # noqa: E402
 
 
-def timeit(fn, iters):
+def timeit(fn, iters, reps=5):
+    """Median / min time of one call in us: `reps` calls back to back between two events (a single call between
+    two events also times the host's gap between the first event and the launch, 5-8 us from Python)."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -27,10 +29,11 @@ def timeit(fn, iters):
     for _ in range(iters):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        fn()
+        for _ in range(reps):
+            fn()
         b.record()
         torch.cuda.synchronize()
-        ts.append(a.elapsed_time(b) * 1e3)
+        ts.append(a.elapsed_time(b) * 1e3 / reps)
     return float(np.median(ts)), float(np.min(ts))
 
 
@@ -44,8 +47,6 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--only", default="", help="comma list of: copy,linear,agg,gcn,gat,norm,misc (default all but gat)")
-    ap.add_argument("--rcb", type=int, default=0, help="renumber the mesh nodes by recursive coordinate bisection "
-                    "with leaves of this many nodes (locality experiment; 0 = reference order)")
     args = ap.parse_args()
     name = "wb2_512x256_19f_ar" if args.config.startswith("wb2") else args.config
     dev = torch.device("cuda:0")
@@ -86,25 +87,7 @@ def main():
         row(f"linear_bwd_all {tag} (dx+dW+db+colsum)", us, mn, 4 * rows * (2 * K + N), 4 * rows * K * N)
 
     from graphcast_lite_amd.models import _graphs
-    if args.rcb:
-        v = np.asarray(m._finest_mesh.vertices)
-
-        def rcb(ids):
-            if len(ids) <= args.rcb:
-                return [ids]
-            pts = v[ids]
-            ax = int(np.argmax(pts.max(0) - pts.min(0)))
-            o = ids[np.argsort(pts[:, ax], kind="stable")]
-            h = (len(o) // 2 + args.rcb - 1) // args.rcb * args.rcb
-            h = min(max(h, args.rcb), len(o) - 1)
-            return rcb(o[:h]) + rcb(o[h:])
-
-        order = np.concatenate(rcb(np.arange(M)))
-        pos = np.empty(M, dtype=np.int64)
-        pos[order] = np.arange(M)
-        m.processing_graph = torch.from_numpy(pos)[m.processing_graph.cpu()].to(dev)
-        print(f"# mesh nodes renumbered by RCB (leaf {args.rcb})")
-    for ei, nn_, tag in () if "agg" not in only else ((m.processing_graph, M, "mesh E_M"), (m.encoding_graph, n, "enc E_G2M"), (m.decoding_graph, n, "dec E_M2G")):
+    for ei, nn_, tag in () if "agg" not in only else ((m.processor_graph(), M, "mesh E_M (tile order)"), (m.encoding_graph, n, "enc E_G2M"), (m.decoding_graph, n, "dec E_M2G")):
         gr = _graphs.get(ei, nn_, hip.GRAPH_GCN)
         h, bias = rnd(B, nn_, F), rnd(F)
         out = torch.empty(B, nn_, F, device=dev)
@@ -115,7 +98,7 @@ def main():
         row(f"aggregate bwd {tag} (transpose)", us, mn, B * per, 2 * B * gr.e * F)
 
     # one-kernel GCNConv layer (aggregate-first): the same per-layer algorithmic bytes as the aggregation
-    for ei, nn_, tag in () if "gcn" not in only else ((m.processing_graph, M, "mesh E_M"), (m.encoding_graph, n, "enc E_G2M"), (m.decoding_graph, n, "dec E_M2G")):
+    for ei, nn_, tag in () if "gcn" not in only else ((m.processor_graph(), M, "mesh E_M (tile order)"), (m.encoding_graph, n, "enc E_G2M"), (m.decoding_graph, n, "dec E_M2G")):
         gr = _graphs.get(ei, nn_, hip.GRAPH_GCN)
         x, W, bias = rnd(B, nn_, F), rnd(F, F) * 0.1, rnd(F)
         out = torch.empty(B, nn_, F, device=dev)
