@@ -21,6 +21,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "halo.h"
 
 namespace {
 
@@ -282,20 +283,10 @@ __global__ __launch_bounds__(256) void agg_heavy_kernel(const int32_t* __restric
 // tile's 128-byte-per-row records for every sample costs 17 us of that difference and the scalar-loaded list 6 us -
 // which is why a block here keeps both in registers across the samples of its XCD group.
 // ---------------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(1))) const void* gcl_gptr_t;
-typedef __attribute__((address_space(3))) void* gcl_lptr_t;
-
-template <int K>
-__device__ __forceinline__ int row_bcast(int v) {  // lane K of every 16-lane row, to all lanes of the row
-  return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xf, 0xf, true);  // bound_ctrl: no `old` operand to set up
-}
-
-// product and sum rounded separately (PyG: message = w * x_j, then scatter_add); `x * y` alone may be contracted
-__device__ __forceinline__ float mul_then_add(float wk, float v, float a) {
-#pragma clang fp contract(off)
-  const float t = wk * v;
-  return a + t;
-}
+using gcl::halo::mul_then_add;
+using gcl::halo::row_bcast;
+typedef gcl::halo::gptr_t gcl_gptr_t;
+typedef gcl::halo::lptr_t gcl_lptr_t;
 
 #ifdef GCL_STAMPS
 __device__ unsigned long long agg_stamps[8 * 4096];  // diagnostic builds only (make STAMPS=1): per wave, cycles per phase

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "halo.h"
 #include "x3.h"
 
 namespace {
@@ -585,6 +586,244 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void gcn_fwd_kernel(
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same layer on graphs that carry a source-tile layout (common.h gcl_halo: mesh rows in tile order): the gather
+// stage is the one of agg_halo_loop_kernel (aggregate.hip) - a block stages a 64-row tile's own rows and its halo
+// once by LDS-DMA and forms the sums from LDS - instead of one L2 gather per edge, which bounds gcn_fwd_kernel on the
+// mesh graph (145 us per layer against 61 us for the source-tile aggregation of the same rows).
+// Block = 4 waves, persistent over a contiguous range of (tile, sample) items, tile-major (list entries and edge
+// records of a tile stay in registers for all samples of the XCD group).  Per item:
+//   wait DMA + barrier | sums of the wave's 16 rows (row_fma<ACT>, CSR order: the arithmetic of gather_tile above, bit
+//   for bit) -> At[pair][32][KP] | barrier (At complete, image free) | DMA of the NEXT item (inline asm: in flight
+//   under what follows) | wave (pair p, half h): acc = At[p] x W[h*32 .. +31]^T on the bf16 pipe (x3) | barrier |
+//   transpose through At[p]'s half h, 16-byte row stores.
+// The wave's weight fragments (all pieces, all k-steps) live in registers, so LDS holds only At (16.9 KB) and the
+// image (31 KB): three blocks per CU, <= 168 VGPRs.
+// ---------------------------------------------------------------------------------------------------------
+// the wave's weight fragments: rows [j0, j0 + 32) of W (output columns), all k-steps, split once per launch into
+// hi / mid / lo bf16 pieces and kept in registers (48 VGPRs) - no LDS image, which is what lets three blocks share a CU
+struct WFrag {
+  bf16x8 f[4][3];  // [k-step][piece hi | mid | lo]
+};
+__device__ __forceinline__ WFrag load_wfrag(const float* __restrict__ W, int j0, int N, int K) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int j = j0 + r;
+  WFrag wf;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = s * 16 + h * 8 + u;
+      v[u] = (j < N && k < K) ? W[(int64_t)j * K + k] : 0.f;
+    }
+    const Pk3 p0 = split2(v[0], v[1]), p1 = split2(v[2], v[3]), p2 = split2(v[4], v[5]), p3 = split2(v[6], v[7]);
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    wf.f[s][0] = __builtin_bit_cast(bf16x8, u32x4_t{p0.h, p1.h, p2.h, p3.h});
+    wf.f[s][1] = __builtin_bit_cast(bf16x8, u32x4_t{p0.m, p1.m, p2.m, p3.m});
+    wf.f[s][2] = __builtin_bit_cast(bf16x8, u32x4_t{p0.l, p1.l, p2.l, p3.l});
+  }
+  return wf;
+}
+
+__device__ __forceinline__ void mfma_half_x3(f32x16& acc, const float* __restrict__ At, int KP, const WFrag& wf, int nks) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const float* ap = At + r * KP + 8 * h;
+  bf16x8 ah[4], am[4], al[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (s < nks) {
+      const float2 f0 = *reinterpret_cast<const float2*>(ap + 16 * s), f1 = *reinterpret_cast<const float2*>(ap + 16 * s + 2);
+      const float2 f2 = *reinterpret_cast<const float2*>(ap + 16 * s + 4), f3 = *reinterpret_cast<const float2*>(ap + 16 * s + 6);
+      const Pk3 p0 = split2(f0.x, f0.y), p1 = split2(f1.x, f1.y), p2 = split2(f2.x, f2.y), p3 = split2(f3.x, f3.y);
+      typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+      ah[s] = __builtin_bit_cast(bf16x8, u32x4_t{p0.h, p1.h, p2.h, p3.h});
+      am[s] = __builtin_bit_cast(bf16x8, u32x4_t{p0.m, p1.m, p2.m, p3.m});
+      al[s] = __builtin_bit_cast(bf16x8, u32x4_t{p0.l, p1.l, p2.l, p3.l});
+    }
+  }
+  // the order of mfma_tile_x3 (smallest products first), so both kernels produce the same bits
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    if (s < nks) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], wf.f[s][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], wf.f[s][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[s], wf.f[s][1], acc, 0, 0, 0);
+    }
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    if (s < nks) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[s], wf.f[s][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], wf.f[s][1], acc, 0, 0, 0);
+    }
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    if (s < nks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], wf.f[s][0], acc, 0, 0, 0);
+}
+
+template <int ACT, int MAXPW>
+__global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
+    const int32_t* __restrict__ list, const int32_t* __restrict__ cnt, const int2* __restrict__ rec,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ opos, const float* __restrict__ w, int32_t smax,
+    const float* __restrict__ X, int64_t ldx, int64_t bsx, const float* __restrict__ slope_p, const float* __restrict__ W,
+    const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy, int64_t bsy, int32_t n, int32_t B, int32_t K,
+    int32_t N, int32_t Nst, int32_t ntiles) {
+  using gcl::halo::glds16;
+  using gcl::halo::row_bcast;
+  extern __shared__ __align__(16) float smem[];
+  constexpr int T = 64, LPR = 16, RPW = 4, NIT = 4, SH = 8;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) const v4f* lds4_t;
+  const int KP = K + 2;
+  const int AtF = 32 * KP > 2048 ? 32 * KP : 2048;                    // floats per pair: the [32][KP] tile, later two [32][32] output stagings
+  float* At = smem;                                                   // [2][AtF]
+  float* imgf = At + 2 * AtF;                                         // [(smax + 1) * 16] float4
+  float4* img = reinterpret_cast<float4*>(imgf);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane >> 4, l = lane & 15, c0 = l * 4;
+  const bool cactive = c0 < K;
+  const unsigned cb = (unsigned)(cactive ? c0 : 0) * 4u, ldb = (unsigned)ldx * 4u;
+  const int hstride = smax - T;
+  const unsigned lds_img = (unsigned)(size_t)((gcl::halo::lptr_t)img);
+  const unsigned lb = lds_img + (unsigned)l * 16u;
+  const int zrow = smax << SH;
+  const int pair = wave >> 1, half = wave & 1;
+  const WFrag wf = load_wfrag(W, half * 32, N, K);
+  if (threadIdx.x < LPR) img[smax * LPR + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float slope = (ACT == gcl::kActPrelu) ? *slope_p : 1.f;
+  float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);  // bias of the four columns this lane stores (added after the transpose)
+  if (bias) {
+    const int oc = half * 32 + (lane & 7) * 4;
+    bq.x = oc < N ? bias[oc] : 0.f; bq.y = oc + 1 < N ? bias[oc + 1] : 0.f;
+    bq.z = oc + 2 < N ? bias[oc + 2] : 0.f; bq.w = oc + 3 < N ? bias[oc + 3] : 0.f;
+  }
+  asm volatile("" : "+v"(bq.x), "+v"(bq.y), "+v"(bq.z), "+v"(bq.w));  // hipcc's wait for these loads: here, not in the loop
+  __syncthreads();
+
+  const int xcd = blockIdx.x & (gcl::kNumXCD - 1);
+  const int J = gridDim.x >> 3, j = blockIdx.x >> 3;
+  const int nsamp = (B - xcd + gcl::kNumXCD - 1) / gcl::kNumXCD;
+  const int items = nsamp * ntiles;  // item = tile * nsamp + sample index
+  const int base = items / J, extra = items - base * J;
+  int m = j * base + min(j, extra);
+  const int mend = m + base + (j < extra ? 1 : 0);
+  if (m >= mend) return;
+
+  int jj[MAXPW], nhalo = 0, tile = -1;
+  int2 rc[NIT];
+  auto new_tile = [&](int t) {  // list entries (scalar loads) and edge records of tile t: kept for all samples of the group
+    tile = t;
+    nhalo = cnt[t] / RPW;
+    const int32_t* __restrict__ tl = list + (int64_t)t * hstride;
+#pragma unroll
+    for (int q = 0; q < MAXPW; ++q) {
+      const int e0 = min((wave + 4 * q) * RPW, hstride - RPW);
+      int jv = tl[e0];
+#pragma unroll
+      for (int r = 1; r < RPW; ++r) {
+        const int jr = tl[e0 + r];
+        jv = sub == r ? jr : jv;
+      }
+      jj[q] = jv;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = t * T + wave * 16 + sub + it * RPW;
+      rc[it] = rec[(int64_t)(row < n ? row : n - 1) * gcl::kHaloRec + l];
+    }
+  };
+  auto stage = [&](int mm) {  // all DMA pieces of item mm (its tile is `tile`)
+    const int s = mm - tile * nsamp;
+    const char* Xc = reinterpret_cast<const char*>(X + (int64_t)(xcd + gcl::kNumXCD * s) * bsx);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = tile * T + wave * 16 + sub + it * RPW;
+      glds16(Xc, __umul24(row < n ? row : n - 1, ldb) + cb, lds_img + (unsigned)((wave * 16 + it * RPW) << SH));
+    }
+#pragma unroll
+    for (int q = 0; q < MAXPW; ++q) {
+      const int p = wave + 4 * q;
+      if (p < nhalo) glds16(Xc, __umul24(jj[q], ldb) + cb, lds_img + (unsigned)((T + p * RPW) << SH));
+    }
+  };
+  new_tile(m / nsamp);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(rc[it].x), "+v"(rc[it].y));  // records are in before any DMA is issued
+  stage(m);
+
+  while (true) {
+    const int s = m - tile * nsamp;
+    const int b = xcd + gcl::kNumXCD * s;
+    const int trow = tile * T;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the item (and its stores of the previous one)
+    __builtin_amdgcn_s_barrier();                       // image complete
+    // ---- sums of this wave's 16 rows: a = sum_e w_e act(x_src), CSR order, fused multiply-adds (row_fma)
+    float* Ap = At + pair * AtF;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = trow + wave * 16 + it * RPW + sub;
+      const int rx = rc[it].x, rw = rc[it].y;
+      const int rxb = (rx & gcl::kHaloPosMask) << SH;
+      f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#define GCL_FUSED_SLOT(Kk)                                              \
+  {                                                                     \
+    const unsigned ad = (unsigned)row_bcast<Kk>(rxb) + lb;              \
+    const float wk = __int_as_float(row_bcast<Kk>(rw));                 \
+    const v4f v = *(lds4_t)ad;                                          \
+    row_fma<ACT>(a01, a23, make_float4(v.x, v.y, v.z, v.w), wk, slope); \
+  }
+      GCL_FUSED_SLOT(0) GCL_FUSED_SLOT(1) GCL_FUSED_SLOT(2) GCL_FUSED_SLOT(3)
+      GCL_FUSED_SLOT(4) GCL_FUSED_SLOT(5) GCL_FUSED_SLOT(6) GCL_FUSED_SLOT(7)
+      const int last = row_bcast<15>(rx);
+      if (__any(row_bcast<8>(rxb) != zrow)) {
+        GCL_FUSED_SLOT(8) GCL_FUSED_SLOT(9) GCL_FUSED_SLOT(10) GCL_FUSED_SLOT(11)
+        GCL_FUSED_SLOT(12) GCL_FUSED_SLOT(13) GCL_FUSED_SLOT(14) GCL_FUSED_SLOT(15)
+        if (__any((last & gcl::kHaloMore) != 0)) {
+          const int rcl = row < n ? row : n - 1;
+          const int end = (last & gcl::kHaloMore) ? rowptr[rcl + 1] : 0;
+          for (int e = rowptr[rcl] + gcl::kHaloRec; e < end; ++e) {
+            const v4f v = *(lds4_t)(((unsigned)opos[e] << SH) + lb);
+            row_fma<ACT>(a01, a23, make_float4(v.x, v.y, v.z, v.w), w[e], slope);
+          }
+        }
+      }
+#undef GCL_FUSED_SLOT
+      if (cactive) {
+        float2* d = reinterpret_cast<float2*>(Ap + (half * 16 + it * RPW + sub) * KP + c0);
+        d[0] = make_float2(a01.x, a01.y);
+        d[1] = make_float2(a23.x, a23.y);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // At complete; every wave is done with the image
+    // ---- the next item's DMA: in flight under the dense part and the stores of this one
+    const bool more = m + 1 < mend;
+    if (more) {
+      const int tn = (m + 1) / nsamp;
+      if (tn != tile) new_tile(tn);
+      stage(m + 1);
+    }
+    // ---- dense part: wave (pair, half) = rows [pair*32, +32) x output columns [half*32, +32)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    mfma_half_x3(acc, Ap, KP, wf, K >> 4);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // both waves of the pair have read At[pair]: its halves become the output staging
+    {
+      f32x16 accv[1] = {acc};
+      const int r0 = trow + pair * 32;
+      const int nr = n - r0 < 32 ? n - r0 : 32;
+      int nst = Nst - half * 32;
+      nst = nst < 0 ? 0 : (nst > 32 ? 32 : nst);
+      store_tile<1>(accv, Ap + half * (32 * 32), Y + (int64_t)b * bsy + (int64_t)r0 * ldy + half * 32, ldy, nr, nst, bq);
+    }
+    if (!more) break;
+    ++m;
+  }
+}
+
 int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
@@ -627,6 +866,39 @@ extern "C" int gcl_gcn_layer_fwd_rows(const gcl_graph_t* g, const float* x, int6
   GCL_CHECK_ARG(x != y, "gcn_layer_fwd: in-place is not supported");
   const int32_t n = g->n;
   GCL_CHECK_ARG(rows_out >= 1 && rows_out <= n, "gcn_layer_fwd: rows_out=%d outside [1, n=%d]", rows_out, n);
+  hipStream_t st = (hipStream_t)stream;
+  {
+    // source-tile form: graphs with a tile layout (mesh rows in tile order), 64-wide rows, split-operand dense part
+    const int halo_on = env_int("GCL_GCN_HALO", 1);  // read per call: the parity test compares the two kernels
+    static const int x3_on = env_int("GCL_X3", 1) && env_int("GCL_X3_GCN", 1);
+    const gcl_halo& hl = g->halo[0][0];
+    const int hp4 = hl.T == 64 ? (int)gcl::cdiv((hl.smax - 64) / 4, 4) : 99;
+    const int KPh = Fin + 2;
+    const size_t ldsh = (size_t)2 * (32 * KPh > 2048 ? 32 * KPh : 2048) * 4 + (size_t)(hl.smax + 1) * 256;
+    if (halo_on && x3_on && g->kind == GCL_GRAPH_GCN && hl.T == 64 && hp4 <= 8 && Fin % 16 == 0 && Fin > 32 && rows_out == n &&
+        ldsh <= 80 * 1024 && (int64_t)n * ldx * 4 < ((int64_t)1 << 31) && n < (1 << 24) && ldx * 4 < (1 << 24) &&
+        (int64_t)n * ldy * 4 < ((int64_t)1 << 31)) {
+      static const int bpc_env = env_int("GCL_GCN_HALO_BPC", 0);
+      const int per_cu = (int)((160 * 1024) / ldsh);
+      const int Jx = 32 * (bpc_env > 0 ? bpc_env : per_cu);
+      dim3 grid((unsigned)(gcl::kNumXCD * Jx));
+      auto go = [&](auto kern) -> int {
+        const int rc = gcl::ensure_dyn_lds((const void*)kern, ldsh);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(256), ldsh, st, hl.list, hl.cnt, reinterpret_cast<const int2*>(hl.rec), g->rowptr,
+                           hl.opos, g->w, hl.smax, x, ldx, bsx, slope, W, bias, y, ldy, bsy, n, B, Fin, Fout, Fout_store,
+                           hl.ntiles);
+        return GCL_OK;
+      };
+      int rc;
+      if (act == GCL_ACT_PRELU) rc = hp4 <= 4 ? go(&gcn_halo_fwd_kernel<gcl::kActPrelu, 4>) : go(&gcn_halo_fwd_kernel<gcl::kActPrelu, 8>);
+      else if (act == GCL_ACT_SILU) rc = hp4 <= 4 ? go(&gcn_halo_fwd_kernel<gcl::kActSilu, 4>) : go(&gcn_halo_fwd_kernel<gcl::kActSilu, 8>);
+      else rc = hp4 <= 4 ? go(&gcn_halo_fwd_kernel<gcl::kActNone, 4>) : go(&gcn_halo_fwd_kernel<gcl::kActNone, 8>);
+      if (rc) return rc;
+      GCL_CHECK_LAUNCH();
+      return GCL_OK;
+    }
+  }
   const int32_t nRT = (int32_t)gcl::cdiv(rows_out, 32);  // only the tiles that hold requested rows are computed
   const int NS = Fout_store > 32 ? 2 : 1;
   constexpr int NW12 = 12, NW8 = 8;
@@ -644,7 +916,6 @@ extern "C" int gcl_gcn_layer_fwd_rows(const gcl_graph_t* g, const float* x, int6
   if (tiles < grid * NWr) grid = gcl::cdiv(tiles, NWr);
   if (B >= gcl::kNumXCD) grid = gcl::cdiv(grid, gcl::kNumXCD) * gcl::kNumXCD;  // XCD-aware schedule needs a multiple of 8
   const int ewidth = g->ell_cover;  // smallest prefix width that covers (almost) every row: the fix-up loop is the slow path
-  hipStream_t st = (hipStream_t)stream;
 #define GCL_GF4(NS_, ACT_, EW_)                \
   do {                                         \
     if (x3) GCL_GF5(NS_, ACT_, EW_, true);     \
@@ -654,8 +925,7 @@ extern "C" int gcl_gcn_layer_fwd_rows(const gcl_graph_t* g, const float* x, int6
   do {                                                                                                              \
     constexpr int NW = X3_ ? NW8 : NW12;                                                                            \
     auto kern = gcn_fwd_kernel<NS_, ACT_, EW_, NW, false, X3_>;                                                              \
-    { static bool lds_set = false;                                                                                   \
-      if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
+    { const int lrc_ = gcl::ensure_dyn_lds((const void*)kern, 160 * 1024); if (lrc_) return lrc_; } \
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, st, g->rowptr, g->col, g->w, g->ecol, g->ew, x, \
                        ldx, bsx, slope, W, bias, y, ldy, bsy, n, B, Fin, Fout, Fout_store, nRT, rows_out);                     \
   } while (0)
@@ -682,12 +952,12 @@ extern "C" int gcl_gcn_layer_fwd_rows(const gcl_graph_t* g, const float* x, int6
     if (B >= gcl::kNumXCD) grid = gcl::cdiv(grid, gcl::kNumXCD) * gcl::kNumXCD;
     if (NS == 2) {
       auto kern = gcn_fwd_kernel<2, gcl::kActNone, 8, NW, true, false>;
-      GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      { const int lrc_ = gcl::ensure_dyn_lds((const void*)kern, 160 * 1024); if (lrc_) return lrc_; }
       hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, st, g->rowptr, g->col, g->w, g->ecol, g->ew, x, ldx,
                          bsx, slope, W, bias, y, ldy, bsy, n, B, Fin, Fout, Fout_store, nRT, rows_out);
     } else {
       auto kern = gcn_fwd_kernel<1, gcl::kActNone, 8, NW, true, false>;
-      GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      { const int lrc_ = gcl::ensure_dyn_lds((const void*)kern, 160 * 1024); if (lrc_) return lrc_; }
       hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, st, g->rowptr, g->col, g->w, g->ecol, g->ew, x, ldx,
                          bsx, slope, W, bias, y, ldy, bsy, n, B, Fin, Fout, Fout_store, nRT, rows_out);
     }

@@ -1249,8 +1249,7 @@ int launch_linear(const float* X, int64_t ldx, const float* in_slope, const floa
 #define GCL_LIN3(NS_, KT_, V_)                                                                                    \
   do {                                                                                                            \
     auto kern = linear_mfma_kernel<NS_, EPI, KT_, V_>;                                                            \
-    { static bool lds_set = false;                                                                          \
-      if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
+    { const int lrc_ = gcl::ensure_dyn_lds((const void*)kern, 160 * 1024); if (lrc_) return lrc_; } \
     hipLaunchKernelGGL(kern, dim3(g.grid), dim3(g.waves * 64), g.lds, st, X, ldx, in_slope, W, ldw, trans, bias,  \
                        Y, ldy, rows, K, N, Z, ldz, z_slope, slope_part, akind, gcl_ablate());                     \
   } while (0)
@@ -1313,8 +1312,7 @@ int launch_gemm(const float* X, int64_t ldx, int akind, const float* slope, cons
                                   return ((e && atoi(e) == 0) || (f && atoi(f) == 0)) ? 0 : 1; }();
   if (x3_tile && !trans && g.mi == 2) {
     auto kern = gemm_tile_x3_kernel<EPI>;
-    { static bool lds_set = false;
-      if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } }
+    { const int lrc_ = gcl::ensure_dyn_lds((const void*)kern, 160 * 1024); if (lrc_) return lrc_; }
     hipLaunchKernelGGL(kern, dim3(g.grid), dim3(256), gtx3_lds(), st, X, ldx, akind, slope, W, ldw, bias, Y, ldy, rows, K, N,
                        Z, ldz, add, ldadd, slope_part, g.nt, g.total, g.per_xcd);
     GCL_CHECK_LAUNCH();
@@ -1324,8 +1322,7 @@ int launch_gemm(const float* X, int64_t ldx, int akind, const float* slope, cons
 #define GCL_GT(T_, MI_)                                                                                           \
   do {                                                                                                            \
     auto kern = gemm_tile_kernel<EPI, T_, MI_>;                                                                   \
-    { static bool lds_set = false;                                                                                \
-      if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
+    { const int lrc_ = gcl::ensure_dyn_lds((const void*)kern, 160 * 1024); if (lrc_) return lrc_; } \
     hipLaunchKernelGGL(kern, dim3(g.grid), dim3(256), gt_lds(MI_), st, X, ldx, akind, slope, W, ldw, bias, Y, ldy, \
                        rows, K, N, Z, ldz, add, ldadd, slope_part, g.nt, g.total, g.per_xcd);                     \
   } while (0)
@@ -1478,8 +1475,7 @@ static int dw_block(const float* dy, int64_t lddy, const float* x, int64_t ldx, 
 #define GCL_DW3(NO_, NC_, V_)                                                                                     \
   do {                                                                                                            \
     auto kern = dw_mfma_kernel<NO_, NC_, V_>;                                                                     \
-    { static bool lds_set = false;                                                                          \
-      if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
+    { const int lrc_ = gcl::ensure_dyn_lds((const void*)kern, 160 * 1024); if (lrc_) return lrc_; } \
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)nct), dim3(256), lds, st, dy, lddy, x, ldx, in_slope, part, \
                        db ? dbpart : nullptr, rows, Fin, Fout, rpb, akind, tile_stride);                          \
   } while (0)
@@ -1632,8 +1628,7 @@ static int bwd_all_impl(const float* dy, int64_t lddy, const float* W, const flo
 #define GCL_FB(NO_, NC_)                                                                                          \
   do {                                                                                                            \
     auto kern = linear_bwd_fused_kernel<NO_, NC_>;                                                                \
-    { static bool lds_set = false;                                                                                \
-      if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
+    { const int lrc_ = gcl::ensure_dyn_lds((const void*)kern, 160 * 1024); if (lrc_) return lrc_; } \
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, dy, lddy, W, x, ldx, in_slope, dx, lddx, rows, Fin,  \
                        Fout, part_dw, db ? part_db : nullptr, colsum_dx ? part_cs : nullptr,                      \
                        want_slope ? part_sl : nullptr);                                                           \

@@ -607,8 +607,7 @@ int x3_linear_bwd(const float* dy, int64_t lddy, const float* W, const float* x,
 #define GCL_X3B(NO_)                                                                                              \
   do {                                                                                                            \
     auto kern = linear_x3_bwd_kernel<NO_>;                                                                        \
-    { static bool lds_set = false;                                                                                \
-      if (!lds_set) { GCL_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); lds_set = true; } } \
+    { const int lrc_ = gcl::ensure_dyn_lds((const void*)kern, 160 * 1024); if (lrc_) return lrc_; } \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, dy, lddy, W, x, ldx, in_slope, dx, lddx, rows, Fin, Fout, \
                        part_dw, part_db, part_cs, part_slope);                                                    \
   } while (0)

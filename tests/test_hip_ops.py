@@ -753,6 +753,30 @@ def test_gcn_layer_fwd_one_kernel(hip, levels, Fin, Fout, B, act):
         assert rel(got, ref) < TOL
 
 
+@pytest.mark.parametrize("levels,Fin,Fout,B,act", [([3, 5], 64, 64, 9, 0), ([3, 5], 64, 64, 64, 1), ([3, 5], 64, 64, 3, 2),
+                                                   ([2, 4], 48, 33, 5, 1), ([3, 5], 64, 19, 2, 0)])
+def test_gcn_layer_fwd_source_tiles(hip, levels, Fin, Fout, B, act, monkeypatch):
+    """Mesh rows in tile order: gcl_gcn_layer_fwd stages a tile's source rows once in LDS (gcn_halo_fwd_kernel) instead
+    of one gather per edge.  Against the oracle's GCNConv (renaming must be invisible) and BIT-equal to the per-edge
+    one-kernel layer (gcn_fwd_kernel), padded 33- / 19-wide outputs included."""
+    g = build_graphs(experiment("baseline", mesh_levels=levels))
+    n = g["M"]
+    ei_t, order, pos = _tiled(g)
+    gh = hip.Graph(ei_t, n, hip.GRAPH_GCN)
+    assert gh.halo_info(False, 64) is not None
+    a = torch.tensor([0.25])
+    x, W, b = rnd(B, n, Fin, seed=1), rnd(Fout, Fin, seed=2, scale=0.2), rnd(Fout, seed=3)
+    xa = _act_ref(x, act, a)
+    ref = torch.stack([P.gcn_conv(xa[i], g["proc"], W, b) for i in range(min(B, 3))])
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GCL_GCN_HALO", mode)
+        outs[mode] = hip.gcn_layer_fwd(gh, x[:, order].contiguous().to(DEV), act, a.to(DEV) if act == 1 else None, W.to(DEV),
+                                       b.to(DEV)).cpu()
+    assert torch.equal(outs["1"], outs["0"]), "source-tile layer and per-edge layer differ in some bit"
+    assert rel(outs["1"][: min(B, 3), pos], ref) < TOL
+
+
 def test_dense_entry_points_with_zero_rows(hip):
     """An empty set of rows is not an error: outputs are empty, weight gradients are zero (or untouched when
     accumulating)."""
