@@ -51,6 +51,30 @@ def test_full_size_forward_backward_parity(name):
         assert abs(new_h.shape[1] - new_o.shape[1]) <= max(4, int(1e-4 * new_o.shape[1]))
 
 
+def test_full_size_interaction_net_two_steps_fp64_arbitrated():
+    """The v2 InteractionNet pipeline on the FULL 512x256 graphs with a 2-step processor (the 12-step model's float64
+    oracle backward needs ~40 GB; two steps fit): loss and EVERY parameter gradient against the float64 oracle under
+    the twice-the-reference-error + 1e-5 rule of tests/parity.py - the same bar as the GCN / GAT configs, at full edge
+    count (302 082 mesh edges, 256-wide edge MLPs).  The 12-step run below keeps its flat 1e-4."""
+    from graphcast_lite_amd.train import batch_loss, get_lat_weights
+
+    def two_steps(cfg):
+        cfg.pipeline.processor.gcn.num_message_passing_steps = 2
+
+    cfg, m, o = make_pair("wb2_512x256_19f_ar_v2", None, nlat=NLAT, nlon=NLON, tweak=two_steps)
+    assert len(m.processor.graph_layer.layers.steps) == 2 and m._num_mesh_nodes == 40962
+    X, y = data(cfg, m._num_grid_nodes, 1)
+    lw = T.get_lat_weights(NLAT, NLON)
+    loss_o = T.train_step_loss(o, X, y, lat_weights=lw)
+    loss_o.backward()
+    loss_h = batch_loss(m, X.to(DEV), y.to(DEV), lat_weights=get_lat_weights(NLAT, NLON, DEV))
+    loss_h.backward()
+    assert abs(float(loss_h) - float(loss_o)) <= 1e-5 * abs(float(loss_o))
+    o64 = oracle_fp64(o)
+    T.train_step_loss(o64, X.double(), y.double(), lat_weights=lw.double()).backward()
+    check_grads(grads_of(m), grads_of(o), grads_of(o64), tag="full size v2, 2 message-passing steps")
+
+
 def test_full_size_interaction_net_forward_backward():
     """wb2_512x256_19f_ar_v2 at full size: forward against the oracle, and the backward of the whole 12-step
     processor against the oracle's autograd (fp32, ~30 s of CPU) for EVERY parameter: the last two message-passing

@@ -30,10 +30,12 @@ def arbitrated_grad_check(m, o, loss_fn64, tag):
     return check_grads(grads_of(m), grads_of(o), grads_of(o64), tag=tag)
 
 
-def make_pair(name, levels, nlat=32, nlon=64, seed=42):
+def make_pair(name, levels, nlat=32, nlon=64, seed=42, tweak=None):
     from graphcast_lite_amd.models import WeatherPrediction
 
     cfg = experiment(name, mesh_levels=levels)
+    if tweak is not None:
+        tweak(cfg)  # e.g. fewer message-passing steps, so a float64 oracle pass fits in host memory at full graph size
     torch.manual_seed(seed)
     lats = np.linspace(-90, 90, nlat, endpoint=True)
     lons = np.linspace(0, 360, nlon, endpoint=False)

@@ -777,6 +777,48 @@ def test_gcn_layer_fwd_source_tiles(hip, levels, Fin, Fout, B, act, monkeypatch)
     assert rel(outs["1"][: min(B, 3), pos], ref) < TOL
 
 
+@pytest.mark.parametrize("rows,Fin,Fout", [(1000, 256, 256), (777, 512, 256), (300, 256, 128), (129, 160, 384)])
+def test_x3_wide_contractions_exact_on_integers(hip, rows, Fin, Fout):
+    """gemm_tile_x3_kernel (csrc/gemm_tile.h: the wide layers of configs[3]/[4] and the InteractionNet MLPs) on small
+    integers: every product and partial sum is exact in fp32, so a wrong operand map, piece image or chunk order
+    shows up as a wrong integer.  Forward (with bias) and dX must be BIT-equal to the float64 result."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randint(-7, 8, (rows, Fin), generator=g).float()
+    W = torch.randint(-5, 6, (Fout, Fin), generator=g).float()
+    W[::3] += 0.5
+    b = torch.randint(-9, 10, (Fout,), generator=g).float()
+    dy = torch.randint(-6, 7, (rows, Fout), generator=g).float()
+    ref = (x.double() @ W.double().t() + b.double()).float()
+    got = hip.dense_fwd(x.to(DEV), W.to(DEV), b.to(DEV), hip.ACT_NONE, None)
+    assert torch.equal(got.cpu(), ref), f"forward differs in {(got.cpu() != ref).sum().item()} elements"
+    dref = (dy.double() @ W.double()).float()
+    dgot = hip.dense_bwd_dx(dy.to(DEV), W.to(DEV), x.to(DEV), hip.ACT_NONE, None, None)
+    assert torch.equal(dgot.cpu(), dref), f"dX differs in {(dgot.cpu() != dref).sum().item()} elements"
+
+
+@pytest.mark.parametrize("n,Fin,Fout,B", [(64 * 9 + 5, 64, 64, 3), (300, 48, 33, 2), (2000, 64, 19, 5)])
+def test_x3_gcn_layer_exact_on_integers(hip, n, Fin, Fout, B, monkeypatch):
+    """The one-kernel GCNConv layer with the dense part on the bf16 pipe (gcn_fwd_kernel<.., X3> and, where the graph
+    carries a source-tile layout, gcn_halo_fwd_kernel): a ring in which every node has exactly four in-edges (three
+    neighbours + its self-loop) gives every edge the weight 1/sqrt(4) * 1/sqrt(4) = 0.25, so with small-integer x and W
+    the aggregated tile, every piece product and every partial sum are exact: the layer must be BIT-equal to float64."""
+    idx = torch.arange(n)
+    ei = torch.stack([torch.cat([(idx + d) % n for d in (-1, 1, 2)]), idx.repeat(3)])
+    gh = hip.Graph(ei, n, hip.GRAPH_GCN)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randint(-7, 8, (B, n, Fin), generator=g).float()
+    W = torch.randint(-5, 6, (Fout, Fin), generator=g).float()
+    W[::3] += 0.5
+    b = torch.randint(-9, 10, (Fout,), generator=g).float()
+    agg = 0.25 * (x.double() + sum(x.double()[:, (idx + d) % n] for d in (-1, 1, 2)))  # receiver i: senders i - 1, i + 1, i + 2 and itself
+    ref = (agg @ W.double().t() + b.double()).float()
+    modes = ("1", "0") if gh.halo_info(False, 64) is not None and Fin % 16 == 0 and Fin > 32 else ("0",)
+    for mode in modes:
+        monkeypatch.setenv("GCL_GCN_HALO", mode)
+        got = hip.gcn_layer_fwd(gh, x.to(DEV), hip.ACT_NONE, None, W.to(DEV), b.to(DEV)).cpu()
+        assert torch.equal(got, ref), f"GCL_GCN_HALO={mode}: {(got != ref).sum().item()} elements differ"
+
+
 def test_dense_entry_points_with_zero_rows(hip):
     """An empty set of rows is not an error: outputs are empty, weight gradients are zero (or untouched when
     accumulating)."""
