@@ -90,6 +90,7 @@ struct gcl_halo {
   int32_t* list = nullptr;   // [ntiles * (smax - T)] sources of a tile OUTSIDE the tile (its halo), ascending, padded by repeating the last
   int32_t* cnt = nullptr;    // [ntiles] halo entries to stage (multiple of 8)
   int32_t* rec = nullptr;    // [n * 16 * 2] {image position | flags (slot 15), weight bits} of the first 16 edges of a row
+                             // (GCL_GRAPH_GAT, transposed direction: the edge's forward CSR slot instead of the weight)
   int32_t* opos = nullptr;   // [E'] image position of every CSR slot (rows with more than 16 edges)
 };
 

@@ -13,9 +13,11 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
+#include "halo.h"
 
 namespace {
 
@@ -444,6 +446,555 @@ __global__ __launch_bounds__(256) void gat_datt_kernel(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Source-tile forward for one head (the reference's GAT / SparseGAT configs run heads = 1: configs[2], [4]) on graphs
+// that carry a tile layout (common.h gcl_halo; mesh rows in tile order): a block stages a 64-row tile's own rows and
+// its halo rows of h once by LDS-DMA (the staging of agg_halo_loop_kernel, aggregate.hip) and does EVERYTHING of the
+// layer from LDS - the scores a_s = <h, att_src>, a_d = <h, att_dst> of the staged rows (no separate scores pass
+// over h), the softmax over a row's in-edges in registers, and the weighted sum - instead of one L2 gather per edge
+// plus one same-address score load per edge.  Persistent blocks, contiguous tile-major (tile, sample) items: a
+// tile's list entries, edge records and CSR offsets stay in registers for all samples of the XCD group.
+//   item: DMA | barrier | scores of the staged rows -> sS[], sD[] (own rows also to a_src / a_dst for the backward)
+//         | barrier | per row: e_k = LeakyReLU(sS[pos_k] + sD[row]), m, sum exp, alpha_k; y = sum alpha_k h[pos_k] + b;
+//         lane k stores alpha_k | barrier (image free)
+// Padded record slots point at the zero row, whose score is -inf: exp() makes them 0 without a select.
+// ---------------------------------------------------------------------------------------------------------
+// value of the lane N places further on in the same 16-lane DPP row (rotation): folds into v_max_f32_dpp / v_add_f32_dpp
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, true));
+}
+
+template <int LPR, int MAXPW>
+__global__ __launch_bounds__(256) void gat_halo_fwd_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ cnt,
+                                                           const int2* __restrict__ rec, const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ opos, int32_t smax,
+                                                           const float* __restrict__ Hf, int64_t ldh, int64_t bsh,
+                                                           const float* __restrict__ att_s, const float* __restrict__ att_d,
+                                                           const float* __restrict__ bias, float* __restrict__ a_src,
+                                                           float* __restrict__ a_dst, float* __restrict__ alpha,
+                                                           float* __restrict__ Y, int64_t ldy, int64_t bsy, int32_t n,
+                                                           int64_t Ep, int32_t B, int32_t C, int32_t ntiles) {
+  using gcl::halo::row_bcast;
+  extern __shared__ float4 img[];  // [(smax + 1) * LPR] staged rows + zero row | sS[smax + 1] | sD[64]
+  constexpr int T = 64, NW = 4;
+  constexpr int RPW = 64 / LPR, NIT = T / NW / RPW;
+  constexpr int SH = LPR == 16 ? 8 : 9;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) const v4f* lds4_t;
+  typedef __attribute__((address_space(3))) const float* ldsf_t;
+  float* sS = reinterpret_cast<float*>(img + (smax + 1) * LPR);
+  float* sD = sS + (smax + 1);
+  const int xcd = blockIdx.x & (gcl::kNumXCD - 1);
+  const int J = gridDim.x >> 3, j = blockIdx.x >> 3;
+  const int nsamp = (B - xcd + gcl::kNumXCD - 1) / gcl::kNumXCD;
+  const int items = nsamp * ntiles;
+  const int base = items / J, extra = items - base * J;
+  int m = j * base + min(j, extra);
+  const int mend = m + base + (j < extra ? 1 : 0);
+  if (m >= mend) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  const unsigned cb = (unsigned)c0 * 4u, ldb = (unsigned)ldh * 4u;
+  const int hstride = smax - T;
+  const unsigned lds0 = (unsigned)(size_t)((gcl::halo::lptr_t)img);
+  const unsigned lb = lds0 + (unsigned)l * 16u;
+  const unsigned ldsS = (unsigned)(size_t)((gcl::halo::lptr_t)sS);
+
+  if (threadIdx.x < LPR) img[smax * LPR + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (threadIdx.x == 0) sS[smax] = -INFINITY;  // the score of a padded slot
+  const float4 as4 = *reinterpret_cast<const float4*>(att_s + c0), ad4 = *reinterpret_cast<const float4*>(att_d + c0);
+  float4 bz = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) bz = *reinterpret_cast<const float4*>(bias + c0);
+  asm volatile("" : "+v"(bz.x), "+v"(bz.y), "+v"(bz.z), "+v"(bz.w));
+
+  int jj[MAXPW], nhalo = 0, tile = -1;
+  int2 rc[NIT];
+  int rstart[NIT];
+  while (true) {
+    const int tnew = m / nsamp;
+    const int s = m - tnew * nsamp;
+    const int b = xcd + gcl::kNumXCD * s;
+    const bool newtile = tnew != tile;
+    if (newtile) {
+      tile = tnew;
+      nhalo = cnt[tile] / RPW;
+      const int32_t* __restrict__ tl = list + (int64_t)tile * hstride;
+#pragma unroll
+      for (int q = 0; q < MAXPW; ++q) {
+        const int e0 = min((wave + NW * q) * RPW, hstride - RPW);
+        int jv = tl[e0];
+#pragma unroll
+        for (int r = 1; r < RPW; ++r) {
+          const int jr = tl[e0 + r];
+          jv = sub == r ? jr : jv;
+        }
+        jj[q] = jv;
+      }
+    }
+    const char* Hc = reinterpret_cast<const char*>(Hf + (int64_t)b * bsh);
+    const int row0 = tile * T + wave * (T / NW) + sub;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = row0 + it * RPW;
+      const char* src = Hc + (__umul24(row < n ? row : n - 1, ldb) + cb);
+      __builtin_amdgcn_global_load_lds((gcl::halo::gptr_t)src, (gcl::halo::lptr_t)(img + (wave * (T / NW) + it * RPW) * LPR), 16, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < MAXPW; ++q) {
+      const int p = wave + NW * q;
+      if (p < nhalo) {
+        const char* src = Hc + (__umul24(jj[q], ldb) + cb);
+        __builtin_amdgcn_global_load_lds((gcl::halo::gptr_t)src, (gcl::halo::lptr_t)(img + (T + p * RPW) * LPR), 16, 0, 0);
+      }
+    }
+    if (newtile) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = row0 + it * RPW;
+        const int rcl = row < n ? row : n - 1;
+        rc[it] = rec[(int64_t)rcl * gcl::kHaloRec + (l & (gcl::kHaloRec - 1))];
+        rstart[it] = rowptr[rcl];
+      }
+    }
+    __syncthreads();  // image complete (vmcnt(0) + barrier)
+
+    // ---- scores of the staged rows: groups of RPW image rows, dealt round-robin to the waves
+    {
+      const int ngroups = T / RPW + nhalo;
+      for (int gq = wave; gq < ngroups; gq += NW) {
+        const int p = gq * RPW + sub;  // image row
+        const v4f v = *(lds4_t)(lds0 + ((unsigned)p << SH) + (unsigned)l * 16u);
+        float ps = v.x * as4.x + v.y * as4.y + v.z * as4.z + v.w * as4.w;
+        float pd = v.x * ad4.x + v.y * ad4.y + v.z * ad4.z + v.w * ad4.w;
+#pragma unroll
+        for (int off = LPR >> 1; off > 0; off >>= 1) {
+          ps += __shfl_xor(ps, off, 64);
+          pd += __shfl_xor(pd, off, 64);
+        }
+        if (l == 0) {
+          sS[p] = ps;
+          if (p < T) {
+            sD[p] = pd;
+            const int row = tile * T + p;
+            if (row < n) {
+              a_src[(int64_t)b * n + row] = ps;
+              a_dst[(int64_t)b * n + row] = pd;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- softmax over the in-edges and weighted sum, per row group
+    float* __restrict__ Yb = Y + (int64_t)b * bsy;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = row0 + it * RPW;
+      const int rloc = wave * (T / NW) + it * RPW + sub;
+      const int rx = rc[it].x;
+      const int rxp = rx & gcl::kHaloPosMask;
+      const int rxb = rxp << SH;
+      const int last = row_bcast<15>(rx);
+      const float adst = sD[rloc];
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      if (!__any((last & gcl::kHaloMore) != 0)) {
+        // lane k of a 16-lane DPP row owns in-edge slot k: ONE score, ONE exp per lane; the row maximum and the
+        // denominator are four rotate-and-combine steps each (v_max_f32_dpp / v_add_f32_dpp row_ror), every lane ends
+        // up with both; the 16 weights are then broadcast slot by slot for the weighted sum
+        const float e = leaky(*(ldsf_t)(ldsS + (unsigned)rxp * 4u) + adst);  // padded slot: -inf
+        float mx = e;
+        mx = fmaxf(mx, row_ror<8>(mx)); mx = fmaxf(mx, row_ror<4>(mx));
+        mx = fmaxf(mx, row_ror<2>(mx)); mx = fmaxf(mx, row_ror<1>(mx));
+        const float ex = expf(e - mx);
+        float den = ex;
+        den += row_ror<8>(den); den += row_ror<4>(den); den += row_ror<2>(den); den += row_ror<1>(den);
+        const float almine = ex * (1.f / (den + 1e-16f));
+        const int ali = __float_as_int(almine);
+        const bool wide = __any(row_bcast<8>(rxb) != (smax << SH));
+#define GCL_GAT_ACC(Kk)                                                          \
+  {                                                                              \
+    const unsigned adr = (unsigned)row_bcast<Kk>(rxb) + lb;                      \
+    const v4f v = *(lds4_t)adr;                                                  \
+    const float al = __int_as_float(row_bcast<Kk>(ali));                         \
+    a0 += al * v.x; a1 += al * v.y; a2 += al * v.z; a3 += al * v.w;              \
+  }
+        GCL_GAT_ACC(0) GCL_GAT_ACC(1) GCL_GAT_ACC(2) GCL_GAT_ACC(3)
+        GCL_GAT_ACC(4) GCL_GAT_ACC(5) GCL_GAT_ACC(6) GCL_GAT_ACC(7)
+        if (wide) {
+          GCL_GAT_ACC(8) GCL_GAT_ACC(9) GCL_GAT_ACC(10) GCL_GAT_ACC(11)
+          GCL_GAT_ACC(12) GCL_GAT_ACC(13) GCL_GAT_ACC(14) GCL_GAT_ACC(15)
+        }
+#undef GCL_GAT_ACC
+        if (alpha && row < n && l < gcl::kHaloRec && rxp != smax) alpha[(int64_t)b * Ep + rstart[it] + l] = almine;
+      } else {
+        // a row of this group has more than 16 in-edges: the CSR arrays give every edge's image position
+        const int rcl = row < n ? row : n - 1;
+        const int st = rowptr[rcl], en = rowptr[rcl + 1];
+        float mx = -INFINITY;
+        for (int e = st; e < en; ++e) mx = fmaxf(mx, leaky(sS[opos[e]] + adst));
+        float den = 0.f;
+        for (int e = st; e < en; ++e) den += expf(leaky(sS[opos[e]] + adst) - mx);
+        const float inv = 1.f / (den + 1e-16f);
+        for (int e = st; e < en; ++e) {
+          const int pk = opos[e];
+          const float al = expf(leaky(sS[pk] + adst) - mx) * inv;
+          const v4f v = *(lds4_t)(((unsigned)pk << SH) + lb);
+          a0 += al * v.x; a1 += al * v.y; a2 += al * v.z; a3 += al * v.w;
+          if (alpha && l == 0 && row < n) alpha[(int64_t)b * Ep + e] = al;
+        }
+      }
+      if (row < n) {
+        float* __restrict__ yp = Yb + (int64_t)row * ldy + c0;
+        *reinterpret_cast<float4*>(yp) = make_float4(a0 + bz.x, a1 + bz.y, a2 + bz.z, a3 + bz.w);
+      }
+    }
+    if (++m >= mend) break;
+    __syncthreads();  // every wave is done with the image and the score arrays
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Source-tile backward for one head (the counterpart of gat_halo_fwd_kernel), two kernels:
+//   dst side (forward tile layout; the image holds h rows): per in-edge slot k of row i
+//       dalpha_k = <dy_i, h[pos_k]>,  t = sum_k alpha_k dalpha_k,  de_k = alpha_k (dalpha_k - t) LeakyReLU'(a_s[src_k] + a_d[i])
+//     lane k of the row's 16-lane DPP row owns slot k (its alpha, its de); the dot products are reduced with four
+//     rotate-and-add steps, so every lane has dalpha_k and lane k keeps it.  a_s of the staged rows arrives by two
+//     4-byte LDS-DMAs (own rows: contiguous; halo rows: by the list).  Writes de[b, slot] and da_d[b, i].
+//   src side (transposed tile layout; the image holds dy rows): per out-edge slot k of source row j
+//       dh_j = sum_k alpha_k dy[dst_k] + (sum_k de_k) att_src + da_d[j] att_dst,  da_s[j] = sum_k de_k
+//     alpha_k / de_k are fetched by the edge's forward CSR slot, which the transposed edge records of a GAT graph
+//     carry in place of a weight.
+// Rows with more than 16 edges take the CSR loop; heavy rows (> 64) keep such graphs on the per-edge kernels.
+// ---------------------------------------------------------------------------------------------------------
+template <int LPR, int MAXPW>
+__global__ __launch_bounds__(256) void gat_halo_bwd_dst_kernel(
+    const int32_t* __restrict__ list, const int32_t* __restrict__ cnt, const int2* __restrict__ rec,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ opos, int32_t smax, const float* __restrict__ dY,
+    int64_t lddy, int64_t bsdy, const float* __restrict__ Hf, int64_t ldh, int64_t bsh, const float* __restrict__ a_s,
+    const float* __restrict__ a_d, const float* __restrict__ alpha, float* __restrict__ de, float* __restrict__ dad,
+    int32_t n, int64_t Ep, int32_t B, int32_t C, int32_t ntiles) {
+  using gcl::halo::row_bcast;
+  extern __shared__ float4 img[];  // [(smax + 1) * LPR] staged h rows + zero row | sS[64 + 128 + 8]: a_s of the staged rows (4-byte DMAs of 64 lanes)
+  constexpr int T = 64, NW = 4;
+  constexpr int RPW = 64 / LPR, NIT = T / NW / RPW;
+  constexpr int SH = LPR == 16 ? 8 : 9;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) const v4f* lds4_t;
+  typedef __attribute__((address_space(3))) const float* ldsf_t;
+  float* sS = reinterpret_cast<float*>(img + (smax + 1) * LPR);
+  const int xcd = blockIdx.x & (gcl::kNumXCD - 1);
+  const int J = gridDim.x >> 3, j = blockIdx.x >> 3;
+  const int nsamp = (B - xcd + gcl::kNumXCD - 1) / gcl::kNumXCD;
+  const int items = nsamp * ntiles;
+  const int base = items / J, extra = items - base * J;
+  int m = j * base + min(j, extra);
+  const int mend = m + base + (j < extra ? 1 : 0);
+  if (m >= mend) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  const unsigned cb = (unsigned)c0 * 4u, ldb = (unsigned)ldh * 4u;
+  const int hstride = smax - T;
+  const unsigned lds0 = (unsigned)(size_t)((gcl::halo::lptr_t)img);
+  const unsigned lb = lds0 + (unsigned)l * 16u;
+  const unsigned ldsS = (unsigned)(size_t)((gcl::halo::lptr_t)sS);
+  if (threadIdx.x < LPR) img[smax * LPR + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (threadIdx.x == 0) sS[smax] = 0.f;
+
+  int jj[MAXPW], nhalo = 0, tile = -1;
+  int hl0 = 0, hl1 = 0;  // wave 0: the halo list, one entry per lane (and lane + 64)
+  int2 rc[NIT];
+  int rstart[NIT];
+  while (true) {
+    const int tnew = m / nsamp;
+    const int s = m - tnew * nsamp;
+    const int b = xcd + gcl::kNumXCD * s;
+    const bool newtile = tnew != tile;
+    if (newtile) {
+      tile = tnew;
+      nhalo = cnt[tile] / RPW;
+      const int32_t* __restrict__ tl = list + (int64_t)tile * hstride;
+#pragma unroll
+      for (int q = 0; q < MAXPW; ++q) {
+        const int e0 = min((wave + NW * q) * RPW, hstride - RPW);
+        int jv = tl[e0];
+#pragma unroll
+        for (int r = 1; r < RPW; ++r) {
+          const int jr = tl[e0 + r];
+          jv = sub == r ? jr : jv;
+        }
+        jj[q] = jv;
+      }
+      if (wave == 0) {
+        hl0 = tl[min(lane, hstride - 1)];
+        hl1 = tl[min(lane + 64, hstride - 1)];
+      }
+    }
+    const char* Hc = reinterpret_cast<const char*>(Hf + (int64_t)b * bsh);
+    const int row0 = tile * T + wave * (T / NW) + sub;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = row0 + it * RPW;
+      const char* src = Hc + (__umul24(row < n ? row : n - 1, ldb) + cb);
+      __builtin_amdgcn_global_load_lds((gcl::halo::gptr_t)src, (gcl::halo::lptr_t)(img + (wave * (T / NW) + it * RPW) * LPR), 16, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < MAXPW; ++q) {
+      const int p = wave + NW * q;
+      if (p < nhalo) {
+        const char* src = Hc + (__umul24(jj[q], ldb) + cb);
+        __builtin_amdgcn_global_load_lds((gcl::halo::gptr_t)src, (gcl::halo::lptr_t)(img + (T + p * RPW) * LPR), 16, 0, 0);
+      }
+    }
+    if (wave == 0) {  // a_s of the staged rows: 4 bytes per lane
+      const float* asb = a_s + (int64_t)b * n;
+      const int r = tile * T + lane;
+      __builtin_amdgcn_global_load_lds((gcl::halo::gptr_t)(asb + (r < n ? r : n - 1)), (gcl::halo::lptr_t)sS, 4, 0, 0);
+      if (nhalo > 0) __builtin_amdgcn_global_load_lds((gcl::halo::gptr_t)(asb + hl0), (gcl::halo::lptr_t)(sS + T), 4, 0, 0);
+      if (nhalo * RPW > 64) __builtin_amdgcn_global_load_lds((gcl::halo::gptr_t)(asb + hl1), (gcl::halo::lptr_t)(sS + T + 64), 4, 0, 0);
+    }
+    if (newtile) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = row0 + it * RPW;
+        const int rcl = row < n ? row : n - 1;
+        rc[it] = rec[(int64_t)rcl * gcl::kHaloRec + (l & (gcl::kHaloRec - 1))];
+        rstart[it] = rowptr[rcl];
+      }
+    }
+    // this item's per-row operands: dy row, a_d, the lane's alpha
+    float4 gy[NIT];
+    float adv[NIT], alv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = row0 + it * RPW;
+      const int rcl = row < n ? row : n - 1;
+      gy[it] = *reinterpret_cast<const float4*>(dY + (int64_t)b * bsdy + (int64_t)rcl * lddy + c0);
+      adv[it] = a_d[(int64_t)b * n + rcl];
+      const bool valid = (rc[it].x & gcl::kHaloPosMask) != smax;
+      alv[it] = alpha[(int64_t)b * Ep + rstart[it] + (valid ? (l & (gcl::kHaloRec - 1)) : 0)];
+    }
+    __syncthreads();  // image + scores complete (vmcnt(0) + barrier)
+
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = row0 + it * RPW;
+      const int rx = rc[it].x;
+      const int rxp = rx & gcl::kHaloPosMask;
+      const int rxb = rxp << SH;
+      const int last = row_bcast<15>(rx);
+      const float4 g4 = gy[it];
+      const float adst = adv[it];
+      const bool valid = rxp != smax;
+      if (!__any((last & gcl::kHaloMore) != 0)) {
+        const int k15 = l & (gcl::kHaloRec - 1);
+        float mine = 0.f;
+        const bool wide = __any(row_bcast<8>(rxb) != (smax << SH));
+#define GCL_GAT_DOT(Kk)                                                                   \
+  {                                                                                       \
+    const unsigned adr = (unsigned)row_bcast<Kk>(rxb) + lb;                               \
+    const v4f v = *(lds4_t)adr;                                                           \
+    float d = g4.x * v.x + g4.y * v.y + g4.z * v.z + g4.w * v.w;                          \
+    d += row_ror<8>(d); d += row_ror<4>(d); d += row_ror<2>(d); d += row_ror<1>(d);       \
+    if (LPR == 32) d += __shfl_xor(d, 16, 64);                                            \
+    mine = k15 == Kk ? d : mine;                                                          \
+  }
+        GCL_GAT_DOT(0) GCL_GAT_DOT(1) GCL_GAT_DOT(2) GCL_GAT_DOT(3)
+        GCL_GAT_DOT(4) GCL_GAT_DOT(5) GCL_GAT_DOT(6) GCL_GAT_DOT(7)
+        if (wide) {
+          GCL_GAT_DOT(8) GCL_GAT_DOT(9) GCL_GAT_DOT(10) GCL_GAT_DOT(11)
+          GCL_GAT_DOT(12) GCL_GAT_DOT(13) GCL_GAT_DOT(14) GCL_GAT_DOT(15)
+        }
+#undef GCL_GAT_DOT
+        const float al = valid ? alv[it] : 0.f;
+        float t = al * mine;
+        t += row_ror<8>(t); t += row_ror<4>(t); t += row_ror<2>(t); t += row_ror<1>(t);
+        const float pre = *(ldsf_t)(ldsS + (unsigned)rxp * 4u) + adst;
+        const float dev = valid ? al * (mine - t) * (pre > 0.f ? 1.f : kNegSlope) : 0.f;
+        float sd = dev;
+        sd += row_ror<8>(sd); sd += row_ror<4>(sd); sd += row_ror<2>(sd); sd += row_ror<1>(sd);
+        if (row < n) {
+          if (valid && l < gcl::kHaloRec) de[(int64_t)b * Ep + rstart[it] + l] = dev;
+          if (l == 0) dad[(int64_t)b * n + row] = sd;
+        }
+      } else {
+        const int rcl = row < n ? row : n - 1;
+        const int st = rowptr[rcl], en = rowptr[rcl + 1];
+        float t = 0.f;
+        for (int e = st; e < en; ++e) {
+          const v4f v = *(lds4_t)(((unsigned)opos[e] << SH) + lb);
+          float d = g4.x * v.x + g4.y * v.y + g4.z * v.z + g4.w * v.w;
+          for (int off = LPR >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+          t += alpha[(int64_t)b * Ep + e] * d;
+        }
+        float sd = 0.f;
+        for (int e = st; e < en; ++e) {
+          const int pk = opos[e];
+          const v4f v = *(lds4_t)(((unsigned)pk << SH) + lb);
+          float d = g4.x * v.x + g4.y * v.y + g4.z * v.z + g4.w * v.w;
+          for (int off = LPR >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+          const float pr = sS[pk] + adst;
+          const float dev = alpha[(int64_t)b * Ep + e] * (d - t) * (pr > 0.f ? 1.f : kNegSlope);
+          sd += dev;
+          if (l == 0 && row < n) de[(int64_t)b * Ep + e] = dev;
+        }
+        if (l == 0 && row < n) dad[(int64_t)b * n + row] = sd;
+      }
+    }
+    if (++m >= mend) break;
+    __syncthreads();
+  }
+}
+
+template <int LPR, int MAXPW>
+__global__ __launch_bounds__(256) void gat_halo_bwd_src_kernel(
+    const int32_t* __restrict__ list, const int32_t* __restrict__ cnt, const int2* __restrict__ rec,
+    const int32_t* __restrict__ trowptr, const int32_t* __restrict__ opos, const int32_t* __restrict__ tslot, int32_t smax,
+    const float* __restrict__ dY, int64_t lddy, int64_t bsdy, const float* __restrict__ alpha, const float* __restrict__ de,
+    const float* __restrict__ dad, const float* __restrict__ att_s, const float* __restrict__ att_d, float* __restrict__ das,
+    float* __restrict__ dH, int64_t lddh, int64_t bsdh, int32_t n, int64_t Ep, int32_t B, int32_t C, int32_t ntiles) {
+  using gcl::halo::row_bcast;
+  extern __shared__ float4 img[];  // [(smax + 1) * LPR] staged dy rows + zero row
+  constexpr int T = 64, NW = 4;
+  constexpr int RPW = 64 / LPR, NIT = T / NW / RPW;
+  constexpr int SH = LPR == 16 ? 8 : 9;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) const v4f* lds4_t;
+  const int xcd = blockIdx.x & (gcl::kNumXCD - 1);
+  const int J = gridDim.x >> 3, j = blockIdx.x >> 3;
+  const int nsamp = (B - xcd + gcl::kNumXCD - 1) / gcl::kNumXCD;
+  const int items = nsamp * ntiles;
+  const int base = items / J, extra = items - base * J;
+  int m = j * base + min(j, extra);
+  const int mend = m + base + (j < extra ? 1 : 0);
+  if (m >= mend) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  const unsigned cb = (unsigned)c0 * 4u, ldb = (unsigned)lddy * 4u;
+  const int hstride = smax - T;
+  const unsigned lds0 = (unsigned)(size_t)((gcl::halo::lptr_t)img);
+  const unsigned lb = lds0 + (unsigned)l * 16u;
+  if (threadIdx.x < LPR) img[smax * LPR + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 as4 = *reinterpret_cast<const float4*>(att_s + c0), ad4 = *reinterpret_cast<const float4*>(att_d + c0);
+
+  int jj[MAXPW], nhalo = 0, tile = -1;
+  int2 rc[NIT];
+  while (true) {
+    const int tnew = m / nsamp;
+    const int s = m - tnew * nsamp;
+    const int b = xcd + gcl::kNumXCD * s;
+    const bool newtile = tnew != tile;
+    if (newtile) {
+      tile = tnew;
+      nhalo = cnt[tile] / RPW;
+      const int32_t* __restrict__ tl = list + (int64_t)tile * hstride;
+#pragma unroll
+      for (int q = 0; q < MAXPW; ++q) {
+        const int e0 = min((wave + NW * q) * RPW, hstride - RPW);
+        int jv = tl[e0];
+#pragma unroll
+        for (int r = 1; r < RPW; ++r) {
+          const int jr = tl[e0 + r];
+          jv = sub == r ? jr : jv;
+        }
+        jj[q] = jv;
+      }
+    }
+    const char* Dc = reinterpret_cast<const char*>(dY + (int64_t)b * bsdy);
+    const int row0 = tile * T + wave * (T / NW) + sub;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = row0 + it * RPW;
+      const char* src = Dc + (__umul24(row < n ? row : n - 1, ldb) + cb);
+      __builtin_amdgcn_global_load_lds((gcl::halo::gptr_t)src, (gcl::halo::lptr_t)(img + (wave * (T / NW) + it * RPW) * LPR), 16, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < MAXPW; ++q) {
+      const int p = wave + NW * q;
+      if (p < nhalo) {
+        const char* src = Dc + (__umul24(jj[q], ldb) + cb);
+        __builtin_amdgcn_global_load_lds((gcl::halo::gptr_t)src, (gcl::halo::lptr_t)(img + (T + p * RPW) * LPR), 16, 0, 0);
+      }
+    }
+    if (newtile) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = row0 + it * RPW;
+        rc[it] = rec[(int64_t)(row < n ? row : n - 1) * gcl::kHaloRec + (l & (gcl::kHaloRec - 1))];
+      }
+    }
+    // this item's per-edge operands of the lane's slot (by forward CSR slot) and the row's da_d
+    float alv[NIT], dev[NIT], ddv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = row0 + it * RPW;
+      const bool valid = (rc[it].x & gcl::kHaloPosMask) != smax;
+      const int64_t sl = (int64_t)b * Ep + (valid ? rc[it].y : 0);
+      alv[it] = alpha[sl];
+      dev[it] = de[sl];
+      ddv[it] = dad[(int64_t)b * n + (row < n ? row : n - 1)];
+    }
+    __syncthreads();
+
+    float* __restrict__ Ob = dH + (int64_t)b * bsdh;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = row0 + it * RPW;
+      const int rx = rc[it].x;
+      const int rxp = rx & gcl::kHaloPosMask;
+      const int rxb = rxp << SH;
+      const int last = row_bcast<15>(rx);
+      const bool valid = rxp != smax;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, sde;
+      if (!__any((last & gcl::kHaloMore) != 0)) {
+        const int ali = __float_as_int(valid ? alv[it] : 0.f);
+        sde = valid ? dev[it] : 0.f;
+        sde += row_ror<8>(sde); sde += row_ror<4>(sde); sde += row_ror<2>(sde); sde += row_ror<1>(sde);
+        const bool wide = __any(row_bcast<8>(rxb) != (smax << SH));
+#define GCL_GAT_ACC(Kk)                                                          \
+  {                                                                              \
+    const unsigned adr = (unsigned)row_bcast<Kk>(rxb) + lb;                      \
+    const v4f v = *(lds4_t)adr;                                                  \
+    const float al = __int_as_float(row_bcast<Kk>(ali));                         \
+    a0 += al * v.x; a1 += al * v.y; a2 += al * v.z; a3 += al * v.w;              \
+  }
+        GCL_GAT_ACC(0) GCL_GAT_ACC(1) GCL_GAT_ACC(2) GCL_GAT_ACC(3)
+        GCL_GAT_ACC(4) GCL_GAT_ACC(5) GCL_GAT_ACC(6) GCL_GAT_ACC(7)
+        if (wide) {
+          GCL_GAT_ACC(8) GCL_GAT_ACC(9) GCL_GAT_ACC(10) GCL_GAT_ACC(11)
+          GCL_GAT_ACC(12) GCL_GAT_ACC(13) GCL_GAT_ACC(14) GCL_GAT_ACC(15)
+        }
+#undef GCL_GAT_ACC
+      } else {
+        const int rcl = row < n ? row : n - 1;
+        sde = 0.f;
+        for (int e = trowptr[rcl]; e < trowptr[rcl + 1]; ++e) {
+          const int64_t sl = (int64_t)b * Ep + tslot[e];
+          const float al = alpha[sl];
+          sde += de[sl];
+          const v4f v = *(lds4_t)(((unsigned)opos[e] << SH) + lb);
+          a0 += al * v.x; a1 += al * v.y; a2 += al * v.z; a3 += al * v.w;
+        }
+      }
+      if (row < n) {
+        const float dd = ddv[it];
+        a0 += sde * as4.x + dd * ad4.x;
+        a1 += sde * as4.y + dd * ad4.y;
+        a2 += sde * as4.z + dd * ad4.z;
+        a3 += sde * as4.w + dd * ad4.w;
+        *reinterpret_cast<float4*>(Ob + (int64_t)row * lddh + c0) = make_float4(a0, a1, a2, a3);
+        if (l == 0) das[(int64_t)b * n + row] = sde;
+      }
+    }
+    if (++m >= mend) break;
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void alpha_reorder_kernel(const int32_t* __restrict__ eperm,
                                                             const float* __restrict__ a_slots,
                                                             float* __restrict__ a_edges, int64_t Ep, int32_t H) {
@@ -516,6 +1067,37 @@ extern "C" int gcl_gat_fwd(const gcl_graph_t* g, const float* h, int64_t ldh, in
   GCL_CHECK_ARG((ldy % 4) == 0 && (bsy % 4) == 0 && gcl::aligned16(y), "gat_fwd: y must be 16-B aligned with ld %% 4 == 0");
   GCL_CHECK_ARG(g->kind == GCL_GRAPH_GAT, "gat_fwd: graph was not created with GCL_GRAPH_GAT");
   hipStream_t st = (hipStream_t)stream;
+  {
+    // one head on a graph with a tile layout: everything of the layer from one LDS image per tile (gat_halo_fwd_kernel)
+    const char* ev = getenv("GCL_GAT_HALO");  // read per call: the parity test compares the two forms
+    const gcl_halo& hl = g->halo[0][0];
+    const int lprh = C / 4;
+    const int64_t ldsb = (int64_t)(hl.smax + 1) * lprh * 16 + (int64_t)(hl.smax + 1 + 64) * 4;
+    if (!(ev && atoi(ev) == 0) && H == 1 && (C == 64 || C == 128) && hl.T == 64 && g->n_heavy == 0 && ldsb <= 80 * 1024 &&
+        (int64_t)g->n * ldh * 4 < ((int64_t)1 << 31) && ldh * 4 < (1 << 24) && g->n < (1 << 24) && gcl::aligned16(att_src) &&
+        gcl::aligned16(att_dst) && (!bias || gcl::aligned16(bias))) {
+      const int rpw = 64 / lprh;
+      const int mpw = (int)gcl::cdiv((hl.smax - 64) / rpw, 4);
+      if (mpw <= 16) {
+        const int per_cu = (int)std::min<int64_t>(8, (160 * 1024) / ldsb);
+        dim3 grid((unsigned)(gcl::kNumXCD * 32 * per_cu));
+        auto go = [&](auto kern) -> int {
+          const int rc2 = gcl::ensure_dyn_lds((const void*)kern, (size_t)ldsb);
+          if (rc2) return rc2;
+          hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)ldsb, st, hl.list, hl.cnt, reinterpret_cast<const int2*>(hl.rec),
+                             g->rowptr, hl.opos, hl.smax, h, ldh, bsh, att_src, att_dst, bias, a_src, a_dst, alpha, y, ldy,
+                             bsy, g->n, g->e, B, C, hl.ntiles);
+          return GCL_OK;
+        };
+        int rc2;
+        if (lprh == 16) rc2 = mpw <= 4 ? go(&gat_halo_fwd_kernel<16, 4>) : mpw <= 8 ? go(&gat_halo_fwd_kernel<16, 8>) : go(&gat_halo_fwd_kernel<16, 16>);
+        else rc2 = mpw <= 4 ? go(&gat_halo_fwd_kernel<32, 4>) : mpw <= 8 ? go(&gat_halo_fwd_kernel<32, 8>) : go(&gat_halo_fwd_kernel<32, 16>);
+        if (rc2) return rc2;
+        GCL_CHECK_LAUNCH();
+        return GCL_OK;
+      }
+    }
+  }
   for (int h0 = 0; h0 < H;) {
     const int hc = chunk_heads(H, h0, maxc);
     const int lpr = lpr_for(hc, C);
@@ -580,6 +1162,53 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
   const int xcd_map = B >= 8 ? 1 : 0;
   const int vdy = (lddy % 4 == 0) && (bsdy % 4 == 0) && (C % 4 == 0) && gcl::aligned16(dy);
   const int64_t rows = (int64_t)B * g->n;
+  bool halo_done = false;
+  {
+    // one head on a graph with tile layouts in both directions: both edge passes from LDS images (gat_halo_bwd_*_kernel)
+    const char* ev = getenv("GCL_GAT_HALO");
+    const gcl_halo& hf = g->halo[0][0];
+    const gcl_halo& ht = g->halo[1][0];
+    const int lprh = C / 4;
+    const int64_t ldsd = (int64_t)(hf.smax + 1) * lprh * 16 + (int64_t)(64 + 128 + 8) * 4;  // image + a_s of up to 64 + 128 staged rows
+    const int64_t ldss = (int64_t)(ht.smax + 1) * lprh * 16;
+    if (!(ev && atoi(ev) == 0) && H == 1 && (C == 64 || C == 128) && hf.T == 64 && ht.T == 64 && g->n_heavy == 0 &&
+        g->n_theavy == 0 && hf.smax - 64 <= 128 && ldsd <= 80 * 1024 && ldss <= 80 * 1024 && vdy &&
+        (int64_t)g->n * ldh * 4 < ((int64_t)1 << 31) && ldh * 4 < (1 << 24) && (int64_t)g->n * lddy * 4 < ((int64_t)1 << 31) &&
+        lddy * 4 < (1 << 24) && g->n < (1 << 24) && gcl::aligned16(att_src) && gcl::aligned16(att_dst)) {
+      const int rpw = 64 / lprh;
+      const int mpd = (int)gcl::cdiv((hf.smax - 64) / rpw, 4), mps = (int)gcl::cdiv((ht.smax - 64) / rpw, 4);
+      if (mpd <= 16 && mps <= 16) {
+        auto god = [&](auto kern) -> int {
+          const int rc2 = gcl::ensure_dyn_lds((const void*)kern, (size_t)ldsd);
+          if (rc2) return rc2;
+          const int per_cu = (int)std::min<int64_t>(8, (160 * 1024) / ldsd);
+          hipLaunchKernelGGL(kern, dim3((unsigned)(gcl::kNumXCD * 32 * per_cu)), dim3(256), (size_t)ldsd, st, hf.list, hf.cnt,
+                             reinterpret_cast<const int2*>(hf.rec), g->rowptr, hf.opos, hf.smax, dy, lddy, bsdy, h, ldh, bsh,
+                             a_src, a_dst, alpha, de, dad, g->n, g->e, B, C, hf.ntiles);
+          return GCL_OK;
+        };
+        auto gos = [&](auto kern) -> int {
+          const int rc2 = gcl::ensure_dyn_lds((const void*)kern, (size_t)ldss);
+          if (rc2) return rc2;
+          const int per_cu = (int)std::min<int64_t>(8, (160 * 1024) / ldss);
+          hipLaunchKernelGGL(kern, dim3((unsigned)(gcl::kNumXCD * 32 * per_cu)), dim3(256), (size_t)ldss, st, ht.list, ht.cnt,
+                             reinterpret_cast<const int2*>(ht.rec), g->trowptr, ht.opos, g->tslot, ht.smax, dy, lddy, bsdy, alpha,
+                             de, dad, att_src, att_dst, das, dh, lddh, bsdh, g->n, g->e, B, C, ht.ntiles);
+          return GCL_OK;
+        };
+        int rc2;
+        if (lprh == 16) rc2 = mpd <= 4 ? god(&gat_halo_bwd_dst_kernel<16, 4>) : mpd <= 8 ? god(&gat_halo_bwd_dst_kernel<16, 8>) : god(&gat_halo_bwd_dst_kernel<16, 16>);
+        else rc2 = mpd <= 4 ? god(&gat_halo_bwd_dst_kernel<32, 4>) : mpd <= 8 ? god(&gat_halo_bwd_dst_kernel<32, 8>) : god(&gat_halo_bwd_dst_kernel<32, 16>);
+        if (rc2) return rc2;
+        GCL_CHECK_LAUNCH();
+        if (lprh == 16) rc2 = mps <= 4 ? gos(&gat_halo_bwd_src_kernel<16, 4>) : mps <= 8 ? gos(&gat_halo_bwd_src_kernel<16, 8>) : gos(&gat_halo_bwd_src_kernel<16, 16>);
+        else rc2 = mps <= 4 ? gos(&gat_halo_bwd_src_kernel<32, 4>) : mps <= 8 ? gos(&gat_halo_bwd_src_kernel<32, 8>) : gos(&gat_halo_bwd_src_kernel<32, 16>);
+        if (rc2) return rc2;
+        GCL_CHECK_LAUNCH();
+        halo_done = true;
+      }
+    }
+  }
   for (int h0 = 0; h0 < H;) {
     const int hc = chunk_heads(H, h0, maxc);
     const int lpr = lpr_for(hc, C);
@@ -587,19 +1216,21 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
     const int32_t nRB = (int32_t)gcl::cdiv(g->n, rpb);
     const unsigned nb = (unsigned)(xcd_map ? (int64_t)8 * gcl::cdiv(B, 8) * nRB : (int64_t)B * nRB);
     const float* hh = h + (int64_t)h0 * C;
+    if (!halo_done) {
 #define CALL(L)                                                                                                    \
   hipLaunchKernelGGL((gat_bwd_dst_kernel<L>), dim3(nb), dim3(256), 0, st, g->rowptr, g->col, g->ecol, dy, lddy,     \
                      bsdy, hh, ldh, bsh, a_src, a_dst, alpha, de, dad, g->n, g->e, B, hc, C, nRB, xcd_map, H, h0, H)
-    GCL_DISPATCH_LPR(lpr, CALL)
+      GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
-    GCL_CHECK_LAUNCH();
+      GCL_CHECK_LAUNCH();
 #define CALL(L)                                                                                                       \
   hipLaunchKernelGGL((gat_bwd_src_kernel<L>), dim3(nb), dim3(256), 0, st, g->trowptr, g->tcol, g->tslot, g->tecol,    \
                      g->teslot, dy, lddy, bsdy, alpha, de, dad, att_src + h0 * C, att_dst + h0 * C, das,              \
                      dh + (int64_t)h0 * C, lddh, bsdh, g->n, g->e, B, hc, C, nRB, vdy, xcd_map, H, h0, H)
-    GCL_DISPATCH_LPR(lpr, CALL)
+      GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
-    GCL_CHECK_LAUNCH();
+      GCL_CHECK_LAUNCH();
+    }
     int64_t nbd = gcl::cdiv(rows, rpb);
     if (nbd > kGatBlocks) nbd = kGatBlocks;
 #define CALL(L)                                                                                                    \

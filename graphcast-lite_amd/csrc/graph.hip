@@ -352,11 +352,16 @@ extern "C" int gcl_graph_create(const int64_t* ei, int64_t E, int32_t n, int32_t
   if (!rc) rc = upload(&g->heavy, hv.data(), hv.size());
   if (!rc) rc = upload(&g->theavy, thv.data(), thv.size());
   // source-tile layouts (forward and transpose, T = 64 and 32)
+  // GAT graphs carry no edge weights: the second word of a TRANSPOSED edge record holds the edge's forward CSR slot
+  // instead (where its attention weight and score gradient live: gat_halo_bwd_src_kernel)
+  std::vector<float> tpay(tw);
+  if (kind == GCL_GRAPH_GAT)
+    for (int64_t e = 0; e < Ep; ++e) memcpy(&tpay[e], &tslot[e], 4);
   for (int d = 0; d < 2 && !rc; ++d)
     for (int t = 0; t < 2 && !rc; ++t) {
       HaloHost hh;
       const bool ok = d == 0 ? build_halo_host(rowptr, col, w, n, t == 0 ? 64 : 32, hh)
-                             : build_halo_host(trowptr, tcol, tw, n, t == 0 ? 64 : 32, hh);
+                             : build_halo_host(trowptr, tcol, tpay, n, t == 0 ? 64 : 32, hh);
       if (!ok) continue;
       gcl_halo& H = g->halo[d][t];
       rc = upload(&H.list, hh.list.data(), hh.list.size());

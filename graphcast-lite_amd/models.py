@@ -591,8 +591,8 @@ class WeatherPrediction(nn.Module):
 
     def _mesh_order(self):
         """(order, pos) int64 CPU tensors: order[new] = old, pos[old] = new; None when the processor keeps the
-        reference numbering (any processor but a GCN stack; GCL_NO_RENUMBER=1)."""
-        if not self._renumber_mesh or self.processor.graph_layer.layer_type != GraphLayerType.ConvGCN:
+        reference numbering (any processor but a GCN or GAT stack; GCL_NO_RENUMBER=1)."""
+        if not self._renumber_mesh or self.processor.graph_layer.layer_type not in (GraphLayerType.ConvGCN, GraphLayerType.GATConv):
             return None
         cached = getattr(self, "_mesh_perm", None)
         if cached is None:

@@ -524,6 +524,58 @@ def test_gat_fwd_bwd(hip, levels, H, C, B):
     assert rel(d_b, b.grad) < TOL
 
 
+@pytest.mark.parametrize("levels,C,B", [([3, 5], 64, 9), ([3, 5], 64, 64), ([2, 4], 128, 3), ([2, 3], 64, 2)])
+def test_gat_fwd_source_tiles(hip, levels, C, B, monkeypatch):
+    """One head on mesh rows in tile order: gcl_gat_fwd does the whole layer from one LDS image per tile
+    (gat_halo_fwd_kernel).  Output, attention weights (edge order) and the saved scores against the oracle's GATConv on
+    the REFERENCE numbering (renaming must be invisible), and against the per-edge kernels on the same graph; the
+    backward then runs on what the forward saved."""
+    g = build_graphs(experiment("baseline", mesh_levels=levels))
+    n, H, Fin = g["M"], 1, 24
+    ei_t, order, pos = _tiled(g)
+    nb = min(B, 3)
+    x = rnd(B, n, Fin, seed=1)
+    W = rnd(C, Fin, seed=2, scale=0.3)
+    a_s, a_d, b = rnd(1, 1, C, seed=3, scale=0.3), rnd(1, 1, C, seed=4, scale=0.3), rnd(C, seed=5)
+    xr = x[:nb].clone().requires_grad_()
+    y_ref, ei2, alpha_ref = P.gat_conv(xr, g["proc"], W, a_s, a_d, b, H)
+    dy = rnd(B, n, C, seed=6)
+    y_ref.backward(dy[:nb])
+    G = hip.Graph(ei_t, n, hip.GRAPH_GAT)
+    assert G.halo_info(False, 64) is not None
+    hd = (x @ W.t())[:, order].contiguous().to(DEV)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GCL_GAT_HALO", mode)
+        outs[mode] = hip.gat_fwd(G, hd, a_s.reshape(-1).to(DEV), a_d.reshape(-1).to(DEV), b.to(DEV), H, C)
+    y, s_src, s_dst, alpha = outs["1"]
+    for a_, b_ in zip(outs["1"], outs["0"]):
+        assert rel(a_, b_) < 2e-6
+    assert rel(y[:nb, pos], y_ref) < TOL
+    # attention weights in PyG edge order: edge e of the reference list is edge e of the renamed list (same order); the
+    # self-loops PyG appends are numbered by node, so theirs follow the renaming
+    al_e = torch.stack([hip.gat_alpha_edge_order(G, alpha[i], H) for i in range(nb)]).cpu()
+    E = g["proc"].shape[1]
+    assert rel(al_e[:, :E], alpha_ref[:, :E]) < TOL and rel(al_e[:, E:][:, pos], alpha_ref[:, E:]) < TOL
+    d_as, d_ad, d_b = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dh = hip.gat_bwd(G, dy[:, order].contiguous().to(DEV), hd, a_s.reshape(-1).to(DEV), a_d.reshape(-1).to(DEV), s_src, s_dst,
+                     alpha, d_as, d_ad, d_b, False, H, C)
+    dx = dh[:nb, pos].cpu().double() @ W.double()
+    assert float((dx - xr.grad).norm() / xr.grad.norm()) < 5e-5
+    # the per-edge backward kernels on the same inputs: same dh and attention-vector gradients
+    monkeypatch.setenv("GCL_GAT_HALO", "0")
+    e_as, e_ad, e_b = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dh0 = hip.gat_bwd(G, dy[:, order].contiguous().to(DEV), hd, a_s.reshape(-1).to(DEV), a_d.reshape(-1).to(DEV), s_src, s_dst,
+                      alpha, e_as, e_ad, e_b, False, H, C)
+    assert float((dh - dh0).norm() / dh0.norm()) < 2e-6
+    assert rel(d_as, e_as) < 2e-5 and rel(d_ad, e_ad) < 2e-5 and rel(d_b, e_b) < 1e-6
+    if B == nb:  # the oracle saw the whole batch: its parameter gradients are comparable
+        a_sr, a_dr = a_s.clone().requires_grad_(), a_d.clone().requires_grad_()
+        yr, _, _ = P.gat_conv(x, g["proc"], W, a_sr, a_dr, b, H)
+        yr.backward(dy)
+        assert rel(d_as.cpu(), a_sr.grad.reshape(-1)) < 5e-5 and rel(d_ad.cpu(), a_dr.grad.reshape(-1)) < 5e-5
+
+
 def test_gat_unsupported_geometry_is_reported(hip):
     g = build_graphs(experiment("baseline", mesh_levels=[0]))
     G = hip.Graph(g["proc"], 12, hip.GRAPH_GAT)

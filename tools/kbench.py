@@ -110,7 +110,11 @@ def main():
     # GATConv / SparseGATConv attention aggregation on the mesh graph (H = 1 head of C = F channels, as configs[2]/[4])
     if "gat" in only:
         H, C = 1, F
-        gr = _graphs.get(m.processing_graph, M, hip.GRAPH_GAT)
+        from graphcast_lite_amd.mesh import tile_order
+        order = torch.from_numpy(np.ascontiguousarray(tile_order(m._finest_mesh.vertices, 64, degree=np.bincount(m.processing_graph[1].cpu().numpy(), minlength=M))))
+        posm = torch.empty(M, dtype=torch.int64)
+        posm[order] = torch.arange(M)
+        gr = hip.Graph(posm[m.processing_graph.cpu()], M, hip.GRAPH_GAT)  # mesh rows in tile order, as the model runs a GAT processor
         h = rnd(B, M, H * C)
         a_s, a_d, bias = rnd(H * C) * 0.3, rnd(H * C) * 0.3, rnd(C)
         # per sample: read h at every edge end is served from cache; algorithmic = h once + y once + alpha + indices
