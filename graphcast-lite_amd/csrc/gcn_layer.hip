@@ -875,7 +875,10 @@ extern "C" int gcl_gcn_layer_fwd_rows(const gcl_graph_t* g, const float* x, int6
     const int hp4 = hl.T == 64 ? (int)gcl::cdiv((hl.smax - 64) / 4, 4) : 99;
     const int KPh = Fin + 2;
     const size_t ldsh = (size_t)2 * (32 * KPh > 2048 ? 32 * KPh : 2048) * 4 + (size_t)(hl.smax + 1) * 256;
+    // only where the gather is the bulk of the layer (>= 6 edges per row: the mesh graph has 7.4): on the decoder graph
+    // of the 512x256 configs (3.3 edges per row) the per-edge kernel's twelve wave-independent pipelines run 1.6x faster
     if (halo_on && x3_on && g->kind == GCL_GRAPH_GCN && hl.T == 64 && hp4 <= 8 && Fin % 16 == 0 && Fin > 32 && rows_out == n &&
+        g->e >= 6 * (int64_t)n &&
         ldsh <= 80 * 1024 && (int64_t)n * ldx * 4 < ((int64_t)1 << 31) && n < (1 << 24) && ldx * 4 < (1 << 24) &&
         (int64_t)n * ldy * 4 < ((int64_t)1 << 31)) {
       static const int bpc_env = env_int("GCL_GCN_HALO_BPC", 0);
