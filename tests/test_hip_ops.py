@@ -851,21 +851,23 @@ def test_x3_wide_contractions_exact_on_integers(hip, rows, Fin, Fout):
 @pytest.mark.parametrize("n,Fin,Fout,B", [(64 * 9 + 5, 64, 64, 3), (300, 48, 33, 2), (2000, 64, 19, 5)])
 def test_x3_gcn_layer_exact_on_integers(hip, n, Fin, Fout, B, monkeypatch):
     """The one-kernel GCNConv layer with the dense part on the bf16 pipe (gcn_fwd_kernel<.., X3> and, where the graph
-    carries a source-tile layout, gcn_halo_fwd_kernel): a ring in which every node has exactly four in-edges (three
-    neighbours + its self-loop) gives every edge the weight 1/sqrt(4) * 1/sqrt(4) = 0.25, so with small-integer x and W
-    the aggregated tile, every piece product and every partial sum are exact: the layer must be BIT-equal to float64."""
+    carries a source-tile layout, gcn_halo_fwd_kernel): a ring in which every node has exactly sixteen in-edges (fifteen
+    neighbours + its self-loop) gives every edge the weight 1/sqrt(16) * 1/sqrt(16) = 1/16, so with small-integer x and
+    W the aggregated tile, every piece product and every partial sum are exact: the layer must be BIT-equal to float64
+    (the sixteen edges also walk both halves of the staged form's edge records)."""
     idx = torch.arange(n)
-    ei = torch.stack([torch.cat([(idx + d) % n for d in (-1, 1, 2)]), idx.repeat(3)])
+    offs = [d for d in range(-7, 9) if d != 0]
+    ei = torch.stack([torch.cat([(idx + d) % n for d in offs]), idx.repeat(len(offs))])
     gh = hip.Graph(ei, n, hip.GRAPH_GCN)
     g = torch.Generator().manual_seed(13)
     x = torch.randint(-7, 8, (B, n, Fin), generator=g).float()
     W = torch.randint(-5, 6, (Fout, Fin), generator=g).float()
     W[::3] += 0.5
     b = torch.randint(-9, 10, (Fout,), generator=g).float()
-    agg = 0.25 * (x.double() + sum(x.double()[:, (idx + d) % n] for d in (-1, 1, 2)))  # receiver i: senders i - 1, i + 1, i + 2 and itself
+    agg = (x.double() + sum(x.double()[:, (idx + d) % n] for d in offs)) / 16.0  # receiver i: senders i + d and itself
     ref = (agg @ W.double().t() + b.double()).float()
-    modes = ("1", "0") if gh.halo_info(False, 64) is not None and Fin % 16 == 0 and Fin > 32 else ("0",)
-    for mode in modes:
+    staged = gh.halo_info(False, 64) is not None and Fin % 16 == 0 and Fin > 32
+    for mode in (("1", "0") if staged else ("0",)):
         monkeypatch.setenv("GCL_GCN_HALO", mode)
         got = hip.gcn_layer_fwd(gh, x.to(DEV), hip.ACT_NONE, None, W.to(DEV), b.to(DEV)).cpu()
         assert torch.equal(got, ref), f"GCL_GCN_HALO={mode}: {(got != ref).sum().item()} elements differ"
