@@ -527,10 +527,9 @@ int launch_agg_halo(const AggArgs& ga, const float* h, int64_t ldh, int64_t bsh,
   }
   if (!hl) return -1;
   const int64_t lds = (int64_t)(hl->smax + 1) * LPR * 16;
-  // wide rows (F = 128: 66 KB images, two blocks per CU) with one sample per XCD group: the per-edge kernel on the
-  // same tile-ordered graph is as fast or faster (79 vs 82 us at 512x256, B = 8: the whole batch sits in the
-  // Infinity Cache); from two samples per group on the staged form wins (155 vs 209 us at B = 16)
-  if (lds > 40 * 1024 && B < 2 * gcl::kNumXCD && !force_t) return -1;
+  // (wide rows, F = 128: 66 KB images, two blocks per CU.  Launched back to back at B = 8 the per-edge kernel on the same
+  // tile-ordered graph is as fast, 79 vs 82 us - the whole batch sits in the Infinity Cache then; inside the training
+  // step it is not, and the staged form wins, 88 vs 102 us per launch, so there is no batch-size switch here.)
   // persistent blocks, as many per CU as LDS allows; every block walks its share of the (tile, sample) items of its XCD group
   const int per_cu = (int)std::min<int64_t>(8, (160 * 1024) / lds);
   const int J = 32 * (bpc_env > 0 ? bpc_env : per_cu);  // blocks per XCD

@@ -722,10 +722,12 @@ class WeatherPrediction(nn.Module):
         if self.use_product_graph:
             X3 = self._product_stage(X3)
         c = getattr(self, "_compact", None) or self._compact_setup(X3.device)
-        if c.Mi > 0 and self._fold_invariant_rows:
-            # the Mi batch-invariant mesh rows ride through the SAME launches as r isolated nodes per sample
+        if self._fold_invariant_rows:
+            # the Mi batch-invariant mesh rows ride through the SAME launches as r isolated nodes per sample; with Mi = 0
+            # (every mesh node has grid senders, e.g. 512x256) the same path runs with r = 0, so the two gradient
+            # consumers of the encoder output still share one landing buffer instead of autograd adding two full tensors
             f = c.fold.get(B) or self._fold_setup(c, B, X3.device)
-            x_c = AssembleFn.apply(X3, self.init_grid_features, f.mstat, f.x_fold)  # [B, G+Md+r, C]
+            x_c = AssembleFn.apply(X3, self.init_grid_features, f.mstat, f.x_fold if f.r > 0 else None)  # [B, G+Md+r, C]
             enc_c = self.encoder.forward(X=x_c, edge_index=c.enc_graph)             # [B, G+Md+r, D]
             land = GradLanding(G) if kwargs.pop("_landing", False) and self._grad_landing else None
             mesh_lat = MeshLatFn.apply(enc_c, f.maps, M, G + c.Md, f.r, land)       # [B, M, D]

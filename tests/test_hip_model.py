@@ -141,8 +141,8 @@ def test_folded_invariant_rows_equal_separate_pass(levels, B):
     if m._compact.Mi > 0:  # (the 162-node mesh has no batch-invariant row: every mesh node has a grid in-edge)
         f = m._compact.fold[B]
         assert f.r == -(-m._compact.Mi // B) and f.ne == m._num_grid_nodes + m._compact.Md + f.r
-    else:
-        assert levels == [1, 2] and not m._compact.fold
+    else:  # the same path with r = 0 folded rows per sample (one shared gradient landing buffer, no folded tail)
+        assert levels == [1, 2] and m._compact.fold[B].r == 0
     m.zero_grad()
     m._fold_invariant_rows = False
     out_s = m(X.to(DEV))
