@@ -444,7 +444,9 @@ def main():
         copy_gbs = copy_ceiling_gbs()
         ms, cnt = probe.mean_ms("gat_fwd")
         ach = B * per_sample / (ms * 1e-3) / 1e9
-        gname = "gat_halo_fwd_kernel" if (Hh == 1 and gg.halo_info(False, 64) and not os.environ.get("GCL_GAT_HALO") == "0") else "gat_fwd_kernel"
+        hi = gg.halo_info(False, 64)
+        staged = Hh == 1 and hi is not None and (hi[2] + 1) * Cc * 4 + (hi[2] + 65) * 4 <= 80 * 1024 and os.environ.get("GCL_GAT_HALO") != "0"
+        gname = "gat_halo_fwd_kernel" if staged else "gat_fwd_kernel"
         roof = {"bound": "hbm", "kernel": f"{gname} (mesh GATConv: scores, softmax over neighbours, aggregation; forward)",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic_of(gname),
                 "bytes_per_launch": B * per_sample, "avg_launch_us": ms * 1e3, "launches_timed": cnt,

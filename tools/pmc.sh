@@ -2,7 +2,8 @@
 # PMC passes (separate runs, as MI355X_MICROARCH.md prescribes) of the kernels matching a name filter,
 # driven by tools/kbench.py.  Run on the GPU box from the repo root:
 #   bash tools/pmc.sh <tag> <kernel-name-substring> [kbench args...]
-# PMC_SCRIPT=tools/halo_check.py profiles another driver script instead of kbench.
+# PMC_SCRIPT=tools/halo_check.py profiles another driver script instead of kbench; PMC_ITERS="" drops the "--iters 3"
+# that kbench / halo_check take (e.g. PMC_SCRIPT=bench.py PMC_ITERS="" bash tools/pmc.sh b bench_kernel --eager --steps 3 ...).
 # Writes gpurun_out/pmc_<tag>/summary.txt (per kernel + grid: mean of every counter, and the kernel-trace
 # duration / VGPR / LDS columns).
 TAG=$1; FILT=$2; shift 2
@@ -12,7 +13,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
   T=$(echo $C | tr ' ' '_' | cut -c1-40)
-  timeout -k 10 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$T -- python3 $R/${PMC_SCRIPT:-tools/kbench.py} --iters 3 "$@" > $OUT/$T.log 2>&1 || echo "pass $T failed" >> $OUT/summary.txt
+  timeout -k 10 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$T -- python3 $R/${PMC_SCRIPT:-tools/kbench.py} ${PMC_ITERS---iters 3} "$@" > $OUT/$T.log 2>&1 || echo "pass $T failed" >> $OUT/summary.txt
 done
 python3 - "$OUT" "$FILT" <<'PY' >> $OUT/summary.txt
 import csv, glob, collections, sys
