@@ -592,7 +592,8 @@ class WeatherPrediction(nn.Module):
     def _mesh_order(self):
         """(order, pos) int64 CPU tensors: order[new] = old, pos[old] = new; None when the processor keeps the
         reference numbering (any processor but a GCN or GAT stack; GCL_NO_RENUMBER=1)."""
-        if not self._renumber_mesh or self.processor.graph_layer.layer_type not in (GraphLayerType.ConvGCN, GraphLayerType.GATConv):
+        if not self._renumber_mesh or self.processor.graph_layer.layer_type not in (
+                GraphLayerType.ConvGCN, GraphLayerType.GATConv, GraphLayerType.SparseGATConv):
             return None
         cached = getattr(self, "_mesh_perm", None)
         if cached is None:
@@ -609,7 +610,7 @@ class WeatherPrediction(nn.Module):
         """The edge list the processor is run on: `processing_graph` itself, or (compact pipeline with a GCN
         processor) the same edges with mesh nodes renamed to tile order.  For callers that look the CSR handle up
         (bench.py's roofline probe); the model's public attributes keep the reference numbering."""
-        if self._compact_eligible() and self._mesh_order() is not None and not (self.using_sparse_gat or self.using_interaction_net):
+        if self._compact_eligible() and self._mesh_order() is not None and not self.using_interaction_net:
             return self._processing_graph_tiled()
         return self.processing_graph
 
@@ -623,6 +624,19 @@ class WeatherPrediction(nn.Module):
             _, pos = self._mesh_order()
             c = self._proc_tiled = (key, pos.to(g.device)[g], g)  # keep g alive: its id must not be reused
         return c[1]
+
+    def _processing_graph_from_tiled(self, tiled: torch.Tensor) -> torch.Tensor:
+        """SparseGATConv hands back the (possibly pruned) edge list it ran on, self-loops included
+        (src/models.py:846): the public `processing_graph` keeps the reference numbering, so the tile-order list is
+        renamed back - once per distinct list; the pair is remembered in both directions, so the next forward finds
+        the SAME tile-order tensor again and the CSR handle cache keeps hitting."""
+        c = getattr(self, "_proc_tiled", None)
+        if c is not None and c[1] is tiled:
+            return c[2]
+        order, _ = self._mesh_order()
+        ref = order.to(tiled.device)[tiled]
+        self._proc_tiled = ((id(ref), ref._version), tiled, ref)
+        return ref
 
     def _compact_setup(self, device):
         G, M = self._num_grid_nodes, self._num_mesh_nodes
@@ -741,9 +755,10 @@ class WeatherPrediction(nn.Module):
             inv = self.encoder.forward(X=c.x_inv, edge_index=c.empty_graph) if c.Mi > 0 else None  # [1, Mi, D]
             mesh_lat = Gather2Fn.apply(enc_c, inv, c.maps_mesh, M, B)                   # [B, M, D]
         if self.using_sparse_gat:
+            pg = self._processing_graph_tiled() if c.perm is not None else self.processing_graph
             processed, new_edge_index = self.processor.forward(
-                X=mesh_lat, edge_index=self.processing_graph, attention_threshold=attention_threshold, **kwargs)
-            self.processing_graph = new_edge_index
+                X=mesh_lat, edge_index=pg, attention_threshold=attention_threshold, **kwargs)
+            self.processing_graph = self._processing_graph_from_tiled(new_edge_index) if c.perm is not None else new_edge_index
         elif self.using_interaction_net:
             processed = self.processor.forward(X=mesh_lat, edge_index=self.processing_graph,
                                                attention_threshold=attention_threshold,
