@@ -1175,7 +1175,10 @@ int launch_reduce_parts3(const float* part, int nparts, int64_t pstride, int pld
 
 namespace {
 
-int gcl_ablate() {  // GCL_ABLATE: timing-only experiments (tools/ablate.sh); 0 unless set
+int gcl_ablate() {  // GCL_ABLATE: timing-only experiments (tools/ablate.sh) - honoured by the diagnostic build only
+#ifndef GCL_STAMPS
+  return 0;  // the product library never turns stores / MFMA / loads off, whatever the environment says
+#endif
   static const int v = [] { const char* e = getenv("GCL_ABLATE"); return e ? atoi(e) : 0; }();
   return v;
 }
@@ -1699,12 +1702,14 @@ extern "C" int gcl_linear_bwd_all_deferred(const float* dy, int64_t lddy, const 
 extern "C" int gcl_reduce_jobs(const gcl_reduce_job* jobs, int32_t n, gcl_stream_t stream) {
   GCL_CHECK_ARG(n >= 0 && (jobs || n == 0), "reduce_jobs: null argument");
   hipStream_t st = (hipStream_t)stream;
-  for (int32_t base = 0; base < n; base += kJobsPerLaunch) {
+  // the running index is carried ACROSS launches: skipped (empty) jobs do not count towards the 16 of a launch, so
+  // restarting at base + 16 would reduce the jobs behind a skipped one twice
+  for (int32_t q = 0; q < n;) {
     RedJobsK J;
     memset(&J, 0, sizeof(J));
     int nb = 0, cnt = 0;
     bool any_slope = false;
-    for (int32_t q = base; q < n && cnt < kJobsPerLaunch; ++q) {
+    for (; q < n && cnt < kJobsPerLaunch; ++q) {
       const gcl_reduce_job& g = jobs[q];
       if (g.nparts <= 0) continue;  // that call reduced on the spot
       GCL_CHECK_ARG(g.part && g.pstride % 4 == 0 && gcl::aligned16(g.part), "reduce_jobs: bad partial buffer");

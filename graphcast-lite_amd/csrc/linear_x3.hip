@@ -524,7 +524,10 @@ __global__ __launch_bounds__(256, 2) void linear_x3_bwd_kernel(
   if (part_slope && tid == 0) part_slope[blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
 }
 
-int x3_ablate() {  // GCL_ABLATE: timing-only experiments (tools/ablate.sh); 0 unless set
+int x3_ablate() {  // GCL_ABLATE: timing-only experiments (tools/ablate.sh) - honoured by the diagnostic build only
+#ifndef GCL_STAMPS
+  return 0;
+#endif
   static const int v = [] { const char* e = getenv("GCL_ABLATE"); return e ? atoi(e) : 0; }();
   return v;
 }

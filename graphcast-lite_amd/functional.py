@@ -205,11 +205,19 @@ class GCNStackFn(torch.autograd.Function):
         land = ctx.land
         dy_map = None
         if land is not None and land.proc_src is not None:
-            # the incoming `dy` is a stride-0 token: the real gradient is the gather's, read through its row map
-            dy_map = (land.proc_src, land.proc_map)
+            if all(st == 0 for st in dy.stride()):
+                # the incoming `dy` is the gather's stride-0 token: the real gradient is the gather's own incoming
+                # gradient, read through its row map
+                dy_map = (land.proc_src, land.proc_map)
+                dy3 = dy
+            else:
+                # something ELSE also sent gradient to the processor's output (a hook, a second consumer): autograd has
+                # summed it with the token into a real tensor, so the shortcut would drop it - materialise the gather's
+                # part and take the ordinary path
+                src, pmap = land.proc_src, land.proc_map
+                dy3 = _flat3(dy) + hip.gather2_rows(src, pmap, None, None, dy.shape[-2], src.shape[0])
             land.proc_src = land.proc_map = None
             land.proc_ready = False
-            dy3 = dy
         else:
             dy3 = _flat3(dy)
         B, n = dy3.shape[0], ctx.n_rows
@@ -499,6 +507,7 @@ class Gather2Fn(torch.autograd.Function):
                 land.buf = torch.empty(ctx.sa, dtype=torch.float32, device=g.device)
                 hip.gather2_rows(g, inv_a, None, None, land.head, ctx.B, out=land.buf[:, : land.head])
                 da = land.buf
+                land.handed_over = True  # MeshLatFn.backward must run and fill the tail rows (checked there / by callers)
             else:
                 da = hip.gather2_rows(g, inv_a, None, None, ctx.sa[1], ctx.B, sum_batch=bc)
         if ctx.sb is not None and ctx.needs_input_grad[1]:
@@ -520,6 +529,7 @@ class GradLanding:
 
     def __init__(self, head: int):
         self.head, self.buf, self.mesh_pending = head, None, False
+        self.handed_over = False  # True between Gather2Fn.backward handing the buffer out and MeshLatFn.backward filling its tail
         # second channel: the processor's output is only consumed by the decoder-input gather, so its gradient is the
         # gather's incoming gradient seen through a row map - the processor's LayerNorm backward reads it that way
         # (gcl_layernorm_bwd_map) instead of a zero-filled dense [B, M, D] tensor
@@ -561,7 +571,7 @@ class MeshLatFn(torch.autograd.Function):
             tmp = hip.gather2_rows(g, inv_fold, None, None, B * ctx.r, B, sum_batch=True)
             hip.copy_rows(tmp.view(B, ctx.r, D), out[:, ctx.gmd:])
         if shared:
-            land.buf, land.mesh_pending = None, False
+            land.buf, land.mesh_pending, land.handed_over = None, False, False
             return None, None, None, None, None, None
         return out, None, None, None, None, None
 

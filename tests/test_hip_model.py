@@ -275,6 +275,26 @@ def test_train_step_with_frozen_processor_and_rollout(monkeypatch):
         assert torch.equal(p, before[n_]), f"frozen parameter {n_} moved"
 
 
+def test_second_consumer_of_the_processor_output_keeps_its_gradient():
+    """`WeatherPrediction.forward` lets the decoder-input gather hand the processor's output gradient over as a
+    stride-0 token + row map (functional.GradLanding).  If anything else ALSO consumes the processor's output, autograd
+    sums its gradient with the token: the stack's backward must notice that the incoming gradient is no longer the
+    token and add the gather's part to it instead of dropping the other consumer's share."""
+    cfg, m1, _ = make_pair("baseline", [1, 2])
+    _, m2, _ = make_pair("baseline", [1, 2])
+    X, _ = data(cfg, m1._num_grid_nodes, 3)
+    m2._grad_landing = False  # plain autograd accumulation: the reference behaviour
+    grads = []
+    for m in (m1, m2):
+        out, _, processed = m.forward_with_latents(X.to(DEV), _landing=True)
+        (out.pow(2).mean() + 0.5 * processed.pow(2).mean()).backward()
+        grads.append({n_: p.grad.clone() for n_, p in m.named_parameters()})
+    gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads[1].values())))
+    for n_, g in grads[1].items():
+        d = float((grads[0][n_].double() - g.double()).norm())
+        assert d <= 1e-5 * float(g.double().norm()) + 1e-7 * gn, n_
+
+
 def test_graph_captured_step_equals_eager():
     """TrainStep replayed from a captured hipGraph follows the same trajectory as eager launches."""
     from graphcast_lite_amd.train import TrainStep, get_lat_weights

@@ -243,6 +243,44 @@ def test_deferred_reductions_equal_immediate(hip):
         assert rel(v, u) < 2e-6
 
 
+def test_reduce_jobs_more_than_one_launch_with_an_empty_job(hip):
+    """gcl_reduce_jobs takes 16 jobs per launch and skips empty ones (`nparts == 0`: that call reduced on the spot,
+    legal input per include/gcl.h).  With 19 jobs and an empty one among the first 16, the jobs behind it must be
+    reduced exactly ONCE (restarting the scan at base + 16 used to reduce job 17 twice: doubled dW with the
+    accumulate bit, doubled slope gradient always)."""
+    import ctypes as C
+
+    n_layers, rows, F = 18, 1500, 64
+    a = torch.tensor([0.25], device=DEV)
+    xs = [rnd(rows, F, seed=100 + k).to(DEV) for k in range(n_layers)]
+    Ws = [rnd(F, F, seed=200 + k, scale=0.2).to(DEV) for k in range(n_layers)]
+    dys = [rnd(rows, F, seed=300 + k).to(DEV) for k in range(n_layers)]
+
+    def run(deferred):
+        dWs = [torch.full((F, F), 1.0, device=DEV) for _ in range(n_layers)]
+        dbs = [torch.full((F,), 1.0, device=DEV) for _ in range(n_layers)]
+        da = torch.zeros(1, device=DEV)
+        if deferred:
+            hip.defer_begin()
+        for k in range(n_layers):
+            hip.linear_bwd_all(dys[k], Ws[k], xs[k], a, da, dWs[k], dbs[k], None, True)  # accumulate onto the 1.0s
+        if deferred:
+            d = hip._deferred
+            jobs = list(d.jobs)
+            assert len(jobs) == n_layers
+            jobs.insert(3, hip.ReduceJob())  # an empty job inside the first launch's window
+            arr = (hip.ReduceJob * len(jobs))(*jobs)
+            hip._check(hip.lib().gcl_reduce_jobs(C.cast(arr, C.c_void_p), len(jobs), hip._stream()))
+            torch.cuda.synchronize()
+            hip.defer_flush(drop=True)
+        return dWs, dbs, da
+
+    (w0, b0, a0), (w1, b1, a1) = run(False), run(True)
+    for k in range(n_layers):
+        assert rel(w1[k], w0[k]) < 2e-6 and rel(b1[k], b0[k]) < 2e-6, k
+    assert rel(a1, a0) < 2e-6
+
+
 def test_linear_mfma_equals_valu(hip, monkeypatch):
     """The fp32 MFMA path and the plain VALU path of the same entry point agree (both fp32 FMA chains)."""
     import os
