@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void gat_halo_bwd_dst_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ opos, int32_t smax, const float* __restrict__ dY,
     int64_t lddy, int64_t bsdy, const float* __restrict__ Hf, int64_t ldh, int64_t bsh, const float* __restrict__ a_s,
     const float* __restrict__ a_d, const float* __restrict__ alpha, float* __restrict__ de, float* __restrict__ dad,
-    int32_t n, int64_t Ep, int32_t B, int32_t C, int32_t ntiles) {
+    float* __restrict__ part, int32_t n, int64_t Ep, int32_t B, int32_t C, int32_t ntiles) {
   using gcl::halo::row_bcast;
   extern __shared__ float4 img[];  // [(smax + 1) * LPR] staged h rows + zero row | sS[64 + 128 + 8]: a_s of the staged rows (4-byte DMAs of 64 lanes)
   constexpr int T = 64, NW = 4;
@@ -692,7 +692,10 @@ __global__ __launch_bounds__(256) void gat_halo_bwd_dst_kernel(
   const int base = items / J, extra = items - base * J;
   int m = j * base + min(j, extra);
   const int mend = m + base + (j < extra ? 1 : 0);
-  if (m >= mend) return;
+  if (m >= mend) {  // a block without items still owns a (zero) partial record
+    for (int idx = threadIdx.x; idx < 2 * LPR * 4; idx += 256) part[(size_t)blockIdx.x * (2 * LPR * 4) + idx] = 0.f;
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
@@ -704,6 +707,9 @@ __global__ __launch_bounds__(256) void gat_halo_bwd_dst_kernel(
   if (threadIdx.x < LPR) img[smax * LPR + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (threadIdx.x == 0) sS[smax] = 0.f;
 
+  // gradients of the attention vectors, accumulated over every row this block handles (the rows are all in the image):
+  //   d att_src += sum_edges de_e h[src_e],   d att_dst += sum_rows da_d[i] h[i]      -> part[block][2][C]
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
   int jj[MAXPW], nhalo = 0, tile = -1;
   int hl0 = 0, hl1 = 0;  // wave 0: the halo list, one entry per lane (and lane + 64)
   int2 rc[NIT];
@@ -820,6 +826,27 @@ __global__ __launch_bounds__(256) void gat_halo_bwd_dst_kernel(
           if (valid && l < gcl::kHaloRec) de[(int64_t)b * Ep + rstart[it] + l] = dev;
           if (l == 0) dad[(int64_t)b * n + row] = sd;
         }
+        {
+          const float live = row < n ? 1.f : 0.f;  // rows past the end repeat the last row's records
+          const int dvi = __float_as_int(dev * live);
+          const v4f hi = *(lds4_t)(lds0 + ((unsigned)(wave * (T / NW) + it * RPW + sub) << SH) + (unsigned)l * 16u);
+          const float sdl = sd * live;
+          d0 += sdl * hi.x; d1 += sdl * hi.y; d2 += sdl * hi.z; d3 += sdl * hi.w;
+#define GCL_GAT_DS(Kk)                                                           \
+  {                                                                              \
+    const unsigned adr = (unsigned)row_bcast<Kk>(rxb) + lb;                      \
+    const v4f v = *(lds4_t)adr;                                                  \
+    const float dk = __int_as_float(row_bcast<Kk>(dvi));                         \
+    s0 += dk * v.x; s1 += dk * v.y; s2 += dk * v.z; s3 += dk * v.w;              \
+  }
+          GCL_GAT_DS(0) GCL_GAT_DS(1) GCL_GAT_DS(2) GCL_GAT_DS(3)
+          GCL_GAT_DS(4) GCL_GAT_DS(5) GCL_GAT_DS(6) GCL_GAT_DS(7)
+          if (wide) {
+            GCL_GAT_DS(8) GCL_GAT_DS(9) GCL_GAT_DS(10) GCL_GAT_DS(11)
+            GCL_GAT_DS(12) GCL_GAT_DS(13) GCL_GAT_DS(14) GCL_GAT_DS(15)
+          }
+#undef GCL_GAT_DS
+        }
       } else {
         const int rcl = row < n ? row : n - 1;
         const int st = rowptr[rcl], en = rowptr[rcl + 1];
@@ -840,12 +867,32 @@ __global__ __launch_bounds__(256) void gat_halo_bwd_dst_kernel(
           const float dev = alpha[(int64_t)b * Ep + e] * (d - t) * (pr > 0.f ? 1.f : kNegSlope);
           sd += dev;
           if (l == 0 && row < n) de[(int64_t)b * Ep + e] = dev;
+          if (row < n) { s0 += dev * v.x; s1 += dev * v.y; s2 += dev * v.z; s3 += dev * v.w; }
         }
         if (l == 0 && row < n) dad[(int64_t)b * n + row] = sd;
+        if (row < n) {
+          const v4f hi = *(lds4_t)(lds0 + ((unsigned)(wave * (T / NW) + it * RPW + sub) << SH) + (unsigned)l * 16u);
+          d0 += sd * hi.x; d1 += sd * hi.y; d2 += sd * hi.z; d3 += sd * hi.w;
+        }
       }
     }
     if (++m >= mend) break;
     __syncthreads();
+  }
+  // per-block partial of the attention-vector gradients: the 16 row groups (4 waves x RPW ... ) of a channel quad, in LDS
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(img);  // [4 * RPW][2][LPR * 4]
+  {
+    float* r_ = red + (size_t)(wave * RPW + sub) * (2 * LPR * 4);
+    *reinterpret_cast<float4*>(r_ + c0) = make_float4(s0, s1, s2, s3);
+    *reinterpret_cast<float4*>(r_ + LPR * 4 + c0) = make_float4(d0, d1, d2, d3);
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * LPR * 4; idx += 256) {
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4 * RPW; ++q) acc += red[(size_t)q * (2 * LPR * 4) + idx];
+    part[(size_t)blockIdx.x * (2 * LPR * 4) + idx] = acc;
   }
 }
 
@@ -855,7 +902,8 @@ __global__ __launch_bounds__(256) void gat_halo_bwd_src_kernel(
     const int32_t* __restrict__ trowptr, const int32_t* __restrict__ opos, const int32_t* __restrict__ tslot, int32_t smax,
     const float* __restrict__ dY, int64_t lddy, int64_t bsdy, const float* __restrict__ alpha, const float* __restrict__ de,
     const float* __restrict__ dad, const float* __restrict__ att_s, const float* __restrict__ att_d, float* __restrict__ das,
-    float* __restrict__ dH, int64_t lddh, int64_t bsdh, int32_t n, int64_t Ep, int32_t B, int32_t C, int32_t ntiles) {
+    float* __restrict__ dH, int64_t lddh, int64_t bsdh, float* __restrict__ part_b, int32_t n, int64_t Ep, int32_t B,
+    int32_t C, int32_t ntiles) {
   using gcl::halo::row_bcast;
   extern __shared__ float4 img[];  // [(smax + 1) * LPR] staged dy rows + zero row
   constexpr int T = 64, NW = 4;
@@ -870,11 +918,16 @@ __global__ __launch_bounds__(256) void gat_halo_bwd_src_kernel(
   const int base = items / J, extra = items - base * J;
   int m = j * base + min(j, extra);
   const int mend = m + base + (j < extra ? 1 : 0);
-  if (m >= mend) return;
+  if (m >= mend) {
+    if (part_b)
+      for (int idx = threadIdx.x; idx < LPR * 4; idx += 256) part_b[(size_t)blockIdx.x * (LPR * 4) + idx] = 0.f;
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
   const unsigned cb = (unsigned)c0 * 4u, ldb = (unsigned)lddy * 4u;
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;  // d bias = column sums of dy: the tile's own rows are in the image
   const int hstride = smax - T;
   const unsigned lds0 = (unsigned)(size_t)((gcl::halo::lptr_t)img);
   const unsigned lb = lds0 + (unsigned)l * 16u;
@@ -981,6 +1034,10 @@ __global__ __launch_bounds__(256) void gat_halo_bwd_src_kernel(
         }
       }
       if (row < n) {
+        if (part_b) {
+          const v4f own = *(lds4_t)(lds0 + ((unsigned)(wave * (T / NW) + it * RPW + sub) << SH) + (unsigned)l * 16u);
+          b0 += own.x; b1 += own.y; b2 += own.z; b3 += own.w;
+        }
         const float dd = ddv[it];
         a0 += sde * as4.x + dd * ad4.x;
         a1 += sde * as4.y + dd * ad4.y;
@@ -992,6 +1049,18 @@ __global__ __launch_bounds__(256) void gat_halo_bwd_src_kernel(
     }
     if (++m >= mend) break;
     __syncthreads();
+  }
+  if (part_b) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(img);  // [4 * RPW][LPR * 4]
+    *reinterpret_cast<float4*>(red + (size_t)(wave * RPW + sub) * (LPR * 4) + c0) = make_float4(b0, b1, b2, b3);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < LPR * 4; idx += 256) {
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4 * RPW; ++q) acc += red[(size_t)q * (LPR * 4) + idx];
+      part_b[(size_t)blockIdx.x * (LPR * 4) + idx] = acc;
+    }
   }
 }
 
@@ -1130,7 +1199,7 @@ extern "C" int gcl_gat_fwd(const gcl_graph_t* g, const float* h, int64_t ldh, in
 extern "C" size_t gcl_gat_bwd_ws_bytes(int64_t e_prime, int32_t n, int32_t B, int32_t H, int32_t C) {
   const size_t de = (size_t)B * e_prime * H;
   const size_t nodes = (size_t)B * n * H * 2;  // da_d, da_s
-  const size_t parts = (size_t)kGatBlocks * 2 * H * C + (size_t)1024 * C;  // + colsum scratch
+  const size_t parts = (size_t)(kGatBlocks > 2048 ? kGatBlocks : 2048) * 2 * H * C + (size_t)2048 * C;  // partial records (<= 2048 blocks) + colsum scratch / d_bias partials
   return (de + nodes + parts) * sizeof(float) + 256;
 }
 
@@ -1158,11 +1227,13 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
   float* dad = de + (size_t)B * g->e * H;
   float* das = dad + (size_t)B * g->n * H;
   float* part = das + (size_t)B * g->n * H;
-  float* cs_ws = part + (size_t)kGatBlocks * 2 * H * C;
+  float* cs_ws = part + (size_t)(kGatBlocks > 2048 ? kGatBlocks : 2048) * 2 * H * C;
   const int xcd_map = B >= 8 ? 1 : 0;
   const int vdy = (lddy % 4 == 0) && (bsdy % 4 == 0) && (C % 4 == 0) && gcl::aligned16(dy);
   const int64_t rows = (int64_t)B * g->n;
   bool halo_done = false;
+  int halo_parts = 0;  // partial records of the attention-vector gradients written by the staged dst-side kernel
+  int halo_bparts = 0;  // partial records of d_bias (column sums of dy) written by the staged src-side kernel
   {
     // one head on a graph with tile layouts in both directions: both edge passes from LDS images (gat_halo_bwd_*_kernel)
     const char* ev = getenv("GCL_GAT_HALO");
@@ -1184,7 +1255,8 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
           const int per_cu = (int)std::min<int64_t>(8, (160 * 1024) / ldsd);
           hipLaunchKernelGGL(kern, dim3((unsigned)(gcl::kNumXCD * 32 * per_cu)), dim3(256), (size_t)ldsd, st, hf.list, hf.cnt,
                              reinterpret_cast<const int2*>(hf.rec), g->rowptr, hf.opos, hf.smax, dy, lddy, bsdy, h, ldh, bsh,
-                             a_src, a_dst, alpha, de, dad, g->n, g->e, B, C, hf.ntiles);
+                             a_src, a_dst, alpha, de, dad, part, g->n, g->e, B, C, hf.ntiles);
+          halo_parts = (int)(gcl::kNumXCD * 32 * per_cu);
           return GCL_OK;
         };
         auto gos = [&](auto kern) -> int {
@@ -1193,7 +1265,8 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
           const int per_cu = (int)std::min<int64_t>(8, (160 * 1024) / ldss);
           hipLaunchKernelGGL(kern, dim3((unsigned)(gcl::kNumXCD * 32 * per_cu)), dim3(256), (size_t)ldss, st, ht.list, ht.cnt,
                              reinterpret_cast<const int2*>(ht.rec), g->trowptr, ht.opos, g->tslot, ht.smax, dy, lddy, bsdy, alpha,
-                             de, dad, att_src, att_dst, das, dh, lddh, bsdh, g->n, g->e, B, C, ht.ntiles);
+                             de, dad, att_src, att_dst, das, dh, lddh, bsdh, d_bias ? cs_ws : nullptr, g->n, g->e, B, C, ht.ntiles);
+          halo_bparts = d_bias ? (int)(gcl::kNumXCD * 32 * per_cu) : 0;
           return GCL_OK;
         };
         int rc2;
@@ -1233,19 +1306,26 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
     }
     int64_t nbd = gcl::cdiv(rows, rpb);
     if (nbd > kGatBlocks) nbd = kGatBlocks;
+    if (halo_done) {
+      nbd = halo_parts;  // the staged dst-side kernel already left one record per block (H = 1: [2][C])
+    } else {
 #define CALL(L)                                                                                                    \
   hipLaunchKernelGGL((gat_datt_kernel<L>), dim3((unsigned)nbd), dim3(256), 0, st, hh, ldh, bsh, das, dad, part, g->n, \
                      B, hc, C, H, h0)
-    GCL_DISPATCH_LPR(lpr, CALL)
+      GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
-    GCL_CHECK_LAUNCH();
+      GCL_CHECK_LAUNCH();
+    }
     const int HC = hc * C;
     rc = gcl::launch_reduce_parts2(part, (int)nbd, 2 * HC, HC, HC, d_att_src + h0 * C, d_att_dst + h0 * C, HC, accumulate,
                                    st);
     if (rc) return rc;
     h0 += hc;
   }
-  if (d_bias) {
+  if (d_bias && halo_bparts > 0) {
+    rc = gcl::launch_reduce_parts(cs_ws, halo_bparts, C, C, d_bias, C, 1, C, accumulate, st);
+    if (rc) return rc;
+  } else if (d_bias) {
     // dy rows are contiguous across the batch (checked above): one flat column sum
     rc = gcl_colsum(dy, lddy, rows, C, d_bias, accumulate, cs_ws, gcl_colsum_ws_bytes(rows, C), stream);
     if (rc) return rc;

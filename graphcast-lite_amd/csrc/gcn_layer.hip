@@ -751,6 +751,9 @@ __global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
 #pragma unroll
   for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(rc[it].x), "+v"(rc[it].y));  // records are in before any DMA is issued
   stage(m);
+#ifdef GCL_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#endif
 
   while (true) {
     const int s = m - tile * nsamp;
@@ -758,6 +761,7 @@ __global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
     const int trow = tile * T;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the item (and its stores of the previous one)
     __builtin_amdgcn_s_barrier();                       // image complete
+    GCL_STAMP(0);  // wait for the item + barrier
     // ---- sums of this wave's 16 rows: a = sum_e w_e act(x_src), CSR order, fused multiply-adds (row_fma)
     float* Ap = At + pair * AtF;
 #pragma unroll
@@ -795,8 +799,10 @@ __global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
         d[1] = make_float2(a23.x, a23.y);
       }
     }
+    GCL_STAMP(1);  // sums -> At
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // At complete; every wave is done with the image
+    GCL_STAMP(2);  // barrier
     // ---- the next item's DMA: in flight under the dense part and the stores of this one
     const bool more = m + 1 < mend;
     if (more) {
@@ -804,13 +810,19 @@ __global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
       if (tn != tile) new_tile(tn);
       stage(m + 1);
     }
+    GCL_STAMP(3);  // DMA issue of the next item
     // ---- dense part: wave (pair, half) = rows [pair*32, +32) x output columns [half*32, +32)
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     mfma_half_x3(acc, Ap, KP, wf, K >> 4);
+#ifdef GCL_STAMPS
+    asm volatile("" ::"v"(acc[0]));
+#endif
+    GCL_STAMP(4);  // split + MFMA
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // both waves of the pair have read At[pair]: its halves become the output staging
+    GCL_STAMP(5);  // barrier
     {
       f32x16 accv[1] = {acc};
       const int r0 = trow + pair * 32;
@@ -819,9 +831,17 @@ __global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
       nst = nst < 0 ? 0 : (nst > 32 ? 32 : nst);
       store_tile<1>(accv, Ap + half * (32 * 32), Y + (int64_t)b * bsy + (int64_t)r0 * ldy + half * 32, ldy, nr, nst, bq);
     }
+    GCL_STAMP(6);  // transpose + stores
+#ifdef GCL_STAMPS
+    stamp_acc[7] += 1;
+#endif
     if (!more) break;
     ++m;
   }
+#ifdef GCL_STAMPS
+  if (lane == 0 && blockIdx.x < 4096 / 4)
+    for (int i = 0; i < 8; ++i) gl_stamps[(blockIdx.x * 4 + wave) * 8 + i] = stamp_acc[i];
+#endif
 }
 
 int env_int(const char* name, int dflt) {
