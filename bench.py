@@ -427,15 +427,17 @@ def main():
         kname = "agg_halo_loop_kernel" if halo else "agg_kernel"
         agg = line("aggregate", f"{kname} (mesh GCNConv aggregate, forward)") or \
             line("aggregate_T", f"{kname} (mesh GCNConv aggregate, transposed CSR = backward of the layer)")
-        fused = line("gcn_layer_fwd", "gcn_fwd_kernel (whole mesh GCNConv layer forward in one launch: gather + dense)")
+        fh = pg.halo_info(False, 64)
+        fname = "gcn_halo_fwd_kernel" if (fh and F % 16 == 0 and 32 < F <= 64 and Ep >= 6 * M and os.environ.get("GCL_GCN_HALO") != "0") else "gcn_fwd_kernel"
+        fused = line("gcn_layer_fwd", f"{fname} (whole mesh GCNConv layer forward in one launch: gather + dense)")
         roof = agg or fused
         if roof is not None:
-            roof = dict(roof, bound="hbm", traffic=traffic_of(kname if roof is agg else "gcn_fwd_kernel"),
+            roof = dict(roof, bound="hbm", traffic=traffic_of(kname if roof is agg else fname),
                         bytes_per_launch=B * per_sample, copy_ceiling_gbs=copy_gbs,
                         achieved_gather_counted_gbs=B * (per_sample + 4 * Ep * F) / (roof["avg_launch_us"] * 1e-6) / 1e9)
             if fused is not None and roof is not fused:
                 # same algorithmic bytes (X in, Y out, CSR): the one-kernel layer replaces linear + aggregate
-                roof["gcn_layer_one_kernel"] = fused
+                roof["gcn_layer_one_kernel"] = dict(fused, traffic=traffic_of(fname))
     if is_gat and probe is not None and probe.events.get("gat_fwd"):
         # GATConv / SparseGATConv processor: the attention aggregation kernel (scores + neighbour softmax + weighted sum).
         # Algorithmic bytes per sample: the GCN aggregation's + 8 n (a_src, a_dst) + 4 E' H when alpha is kept
