@@ -9,7 +9,7 @@
 // row's <= ~13 in-edges itself (the per-edge scalars a_s[col_e,h] are same-address loads across the
 // head's lanes and come from L1/L2): the neighbour softmax needs no cross-lane traffic at all, and
 // the only shuffles are the head-mean in the epilogue (forward) and the C-channel dot products
-// (backward).  Constraints: C % 4 == 0, C/4 and H powers of two, H*C <= 256.
+// (backward).  Constraints per launch: C % 4 == 0, C <= 256; other head counts / widths run as head chunks (gat_check).
 #include <math.h>
 #include <stdlib.h>
 
@@ -24,21 +24,44 @@ namespace {
 constexpr float kNegSlope = 0.2f;
 __device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : kNegSlope * x; }
 
+// Lane -> channel map of the per-edge kernels.  A head occupies Cp / 4 lanes, Cp = the head width C rounded up to a
+// power-of-two number of 4-channel lanes (C = 48 -> 16 lanes, C = 96 -> 32), so the in-head reductions stay xor
+// butterflies for ANY C % 4 == 0; the lanes of a head beyond C are idle (they contribute zeros).  Cp == C for the
+// power-of-two widths, where the map is the plain l * 4.
+struct LaneMap {
+  int h, cc, c0;  // head of the launch's chunk, channel inside the head, column of h / att (= h * C + cc)
+  bool cact;      // the lane owns four real channels
+  bool hact;      // the lane lies in a real head (it may still be one of the head's idle lanes)
+};
+__device__ __forceinline__ LaneMap lane_map(int l, int H, int C, int Cp) {
+  LaneMap m;
+  const int pc = l * 4;
+  const int hd = pc / Cp;
+  m.cc = pc - hd * Cp;
+  m.hact = hd < H;
+  m.cact = m.hact && m.cc < C;
+  m.h = m.hact ? hd : 0;
+  if (!m.cact) m.cc = 0;
+  m.c0 = m.h * C + m.cc;
+  return m;
+}
+
 // a_s[r,h] = <h[r,h,:], att_src[h,:]>, a_d likewise.  rows = B*n flattened via (ld, bs).
 template <int LPR>
 __global__ __launch_bounds__(256) void gat_scores_kernel(const float* __restrict__ Hf, int64_t ldh, int64_t bsh,
                                                          const float* __restrict__ att_s,
                                                          const float* __restrict__ att_d, float* __restrict__ a_s,
                                                          float* __restrict__ a_d, int32_t n, int32_t B, int32_t H,
-                                                         int32_t C, int32_t Hs, int32_t h0) {
+                                                         int32_t C, int32_t Cp, int32_t Hs, int32_t h0) {
   // H = heads of THIS launch (a chunk of the layer's heads when H_total * C > 256 or H_total is not a power of
   // two); per-head arrays are indexed [.., Hs] at head offset h0 (Hs = H_total, h0 = first head of the chunk)
   constexpr int RPW = 64 / LPR, RPB = RPW * 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
-  const int HC = H * C;
-  const int lph = C >> 2;  // lanes per head
-  const bool cact = c0 < HC;
+  const int sub = lane / LPR, l = lane % LPR;
+  const int lph = Cp >> 2;  // lanes per head
+  const LaneMap lm = lane_map(l, H, C, Cp);
+  const int c0 = lm.c0;
+  const bool cact = lm.cact;
   float s0 = 0, s1 = 0, s2 = 0, s3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0;
   if (cact) {
     s0 = att_s[c0]; s1 = att_s[c0 + 1]; s2 = att_s[c0 + 2]; s3 = att_s[c0 + 3];
@@ -59,7 +82,7 @@ __global__ __launch_bounds__(256) void gat_scores_kernel(const float* __restrict
       pd += __shfl_xor(pd, off, 64);
     }
     if (cact && (l % lph) == 0) {
-      const int h = c0 / C;
+      const int h = lm.h;
       a_s[r * Hs + h0 + h] = ps;
       a_d[r * Hs + h0 + h] = pd;
     }
@@ -74,8 +97,8 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict_
                                                       const float* __restrict__ a_d, const float* __restrict__ bias,
                                                       float* __restrict__ alpha, float* __restrict__ Y, int64_t ldy,
                                                       int64_t bsy, int32_t n, int64_t Ep, int32_t B, int32_t H,
-                                                      int32_t C, int32_t nRB, int32_t xcd_map, int32_t Hs, int32_t h0,
-                                                      int32_t Htot, int32_t yacc) {
+                                                      int32_t C, int32_t Cp, int32_t nRB, int32_t xcd_map, int32_t Hs,
+                                                      int32_t h0, int32_t Htot, int32_t yacc) {
   constexpr int RPW = 64 / LPR, RPB = RPW * 4;
   constexpr int EL = LPR < gcl::kEll ? LPR : gcl::kEll;
   const int bid = blockIdx.x;
@@ -90,14 +113,15 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict_
   }
   if (b >= B) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  const int sub = lane / LPR, l = lane % LPR;
   const int gbase = sub * LPR;
   const int row = rb * RPB + wave * RPW + sub;
-  const int HC = H * C, lph = C >> 2;
-  const bool cact = c0 < HC;
+  const int lph = Cp >> 2;
+  const LaneMap lm = lane_map(l, H, C, Cp);
+  const bool cact = lm.cact;
   const bool active = (row < n) && cact;
-  const int cc = cact ? c0 : 0;
-  const int h = cc / C;
+  const int cc = lm.c0;  // column of h (0 for an idle lane)
+  const int h = lm.h;
   const int rc = row < n ? row : n - 1;
   const float* __restrict__ Hb = Hf + (int64_t)b * bsh;
   const float* __restrict__ as_b = a_s + (int64_t)b * n * Hs + h0;
@@ -137,7 +161,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict_
       for (int off = EL >> 1; off > 0; off >>= 1) den += __shfl_xor(den, off, 64);
       den = __shfl(den, hbase, 64);
       const float almine = ex * (1.f / (den + 1e-16f));
-      if (alpha && mine && active) alpha[((int64_t)b * Ep + start + hl) * Hs + h0 + h] = almine;
+      if (alpha && mine && row < n && lm.hact) alpha[((int64_t)b * Ep + start + hl) * Hs + h0 + h] = almine;
 #pragma unroll
       for (int k = 0; k < EL; ++k) {
         const float al = __shfl(almine, hbase + k, 64);
@@ -195,6 +219,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict_
   }
   if (active && h == 0) {
     const float s = 1.f / (float)Htot;  // mean over ALL heads of the layer; later chunks add onto the first one's result
+    const int c0 = lm.cc;  // head 0: the output channel
     float* yp = Y + (int64_t)b * bsy + (int64_t)row * ldy + c0;
     float o0 = a0 * s, o1 = a1 * s, o2 = a2 * s, o3 = a3 * s;
     if (bias) { o0 += bias[c0]; o1 += bias[c0 + 1]; o2 += bias[c0 + 2]; o3 += bias[c0 + 3]; }
@@ -218,8 +243,8 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const int32_t* __restr
                                                           const float* __restrict__ a_s, const float* __restrict__ a_d,
                                                           const float* __restrict__ alpha, float* __restrict__ de,
                                                           float* __restrict__ dad, int32_t n, int64_t Ep, int32_t B,
-                                                          int32_t H, int32_t C, int32_t nRB, int32_t xcd_map, int32_t Hs,
-                                                          int32_t h0, int32_t Htot) {
+                                                          int32_t H, int32_t C, int32_t Cp, int32_t nRB, int32_t xcd_map,
+                                                          int32_t Hs, int32_t h0, int32_t Htot) {
   constexpr int RPW = 64 / LPR, RPB = RPW * 4;
   constexpr int EL = LPR < gcl::kEll ? LPR : gcl::kEll;
   // all row blocks of a sample on ONE XCD (blocks are dealt round-robin): its h rows stay in that L2
@@ -234,15 +259,16 @@ __global__ __launch_bounds__(256) void gat_bwd_dst_kernel(const int32_t* __restr
   }
   if (b >= B) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  const int sub = lane / LPR, l = lane % LPR;
   const int gbase = sub * LPR;
   const int row = rb * RPB + wave * RPW + sub;
-  const int HC = H * C, lph = C >> 2;
-  const bool cact = c0 < HC;
+  const int lph = Cp >> 2;
+  const LaneMap lm = lane_map(l, H, C, Cp);
+  const bool cact = lm.cact;
   const bool active = (row < n) && cact;
-  const int cc0 = cact ? c0 : 0;
-  const int h = cc0 / C;
-  const int cc = cc0 - h * C;  // channel inside the head = channel of dy
+  const int cc0 = lm.c0;
+  const int h = lm.h;
+  const int cc = lm.cc;  // channel inside the head = channel of dy
   const int rc = row < n ? row : n - 1;
   const float* __restrict__ Hb = Hf + (int64_t)b * bsh;
   const float* __restrict__ as_b = a_s + (int64_t)b * n * Hs + h0;
@@ -325,8 +351,8 @@ __global__ __launch_bounds__(256) void gat_bwd_src_kernel(const int32_t* __restr
                                                           const float* __restrict__ att_d, float* __restrict__ das,
                                                           float* __restrict__ dH, int64_t lddh, int64_t bsdh,
                                                           int32_t n, int64_t Ep, int32_t B, int32_t H, int32_t C,
-                                                          int32_t nRB, int32_t vdy, int32_t xcd_map, int32_t Hs, int32_t h0,
-                                                          int32_t Htot) {
+                                                          int32_t Cp, int32_t nRB, int32_t vdy, int32_t xcd_map, int32_t Hs,
+                                                          int32_t h0, int32_t Htot) {
   constexpr int RPW = 64 / LPR, RPB = RPW * 4;
   constexpr int EL = LPR < gcl::kEll ? LPR : gcl::kEll;
   int b, rb;
@@ -340,14 +366,13 @@ __global__ __launch_bounds__(256) void gat_bwd_src_kernel(const int32_t* __restr
   }
   if (b >= B) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  const int sub = lane / LPR, l = lane % LPR;
   const int gbase = sub * LPR;
   const int row = rb * RPB + wave * RPW + sub;
-  const int HC = H * C, lph = C >> 2;
-  const bool cact = c0 < HC;
-  const bool active = (row < n) && cact;
-  const int cc0 = cact ? c0 : 0;
-  const int h = cc0 / C, cc = cc0 - h * C;
+  const int lph = Cp >> 2;
+  const LaneMap lm = lane_map(l, H, C, Cp);
+  const bool active = (row < n) && lm.cact;
+  const int c0 = lm.c0, h = lm.h, cc = lm.cc;
   const int rc = row < n ? row : n - 1;
   const float s = 1.f / (float)Htot;
   const int start = trowptr[rc], end = trowptr[rc + 1];
@@ -414,14 +439,15 @@ template <int LPR>
 __global__ __launch_bounds__(256) void gat_datt_kernel(const float* __restrict__ Hf, int64_t ldh, int64_t bsh,
                                                        const float* __restrict__ das, const float* __restrict__ dad,
                                                        float* __restrict__ part, int32_t n, int32_t B, int32_t H,
-                                                       int32_t C, int32_t Hs, int32_t h0) {
+                                                       int32_t C, int32_t Cp, int32_t Hs, int32_t h0) {
   constexpr int RPW = 64 / LPR, RPB = RPW * 4;
   __shared__ float red[RPB][LPR * 4 * 2 + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
+  const int sub = lane / LPR, l = lane % LPR;
   const int HC = H * C;
-  const bool cact = c0 < HC;
-  const int h = cact ? c0 / C : 0;
+  const LaneMap lm = lane_map(l, H, C, Cp);
+  const bool cact = lm.cact;
+  const int h = lm.h, c0 = lm.c0;
   float s0 = 0, s1 = 0, s2 = 0, s3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0;
   const int64_t rows = (int64_t)B * n;
   if (cact)
@@ -434,8 +460,10 @@ __global__ __launch_bounds__(256) void gat_datt_kernel(const float* __restrict__
       d0 += wd * v.x; d1 += wd * v.y; d2 += wd * v.z; d3 += wd * v.w;
     }
   float* r_ = red[wave * RPW + sub];
-  r_[c0] = s0; r_[c0 + 1] = s1; r_[c0 + 2] = s2; r_[c0 + 3] = s3;
-  r_[LPR * 4 + c0] = d0; r_[LPR * 4 + c0 + 1] = d1; r_[LPR * 4 + c0 + 2] = d2; r_[LPR * 4 + c0 + 3] = d3;
+  if (cact) {  // every column < HC is owned by exactly one lane of the row group; the idle lanes of a padded head write nothing
+    r_[c0] = s0; r_[c0 + 1] = s1; r_[c0 + 2] = s2; r_[c0 + 3] = s3;
+    r_[LPR * 4 + c0] = d0; r_[LPR * 4 + c0 + 1] = d1; r_[LPR * 4 + c0 + 2] = d2; r_[LPR * 4 + c0 + 3] = d3;
+  }
   __syncthreads();
   for (int idx = threadIdx.x; idx < 2 * LPR * 4; idx += 256) {
     float s = 0.f;
@@ -1089,21 +1117,27 @@ constexpr int kGatBlocks = 512;
 // channels), so one launch takes a power-of-two number of heads Hc with Hc * C <= 256.  A layer with more heads, or
 // a head count that is not a power of two (the reference reports 8 and 33 heads at C = 64, README.md:148-150),
 // runs as several launches over column blocks of h, with per-head arrays strided by the total head count.
+// head width rounded up to a power-of-two number of 4-channel lanes (lane_map)
+inline int padded_width(int C) {
+  int lph = 1;
+  while (lph * 4 < C) lph *= 2;
+  return lph * 4;
+}
 int gat_check(const gcl_graph_t* g, int32_t H, int32_t C, int* chunk) {
   GCL_CHECK_ARG(g, "gat: null graph");
   GCL_CHECK_ARG(H >= 1 && C >= 4 && (C % 4) == 0, "gat: C must be a positive multiple of 4 (H=%d C=%d)", H, C);
-  const int lph = C / 4;
-  if ((lph & (lph - 1)) != 0 || C > 256) {
-    gcl::set_error("gat: unsupported head width C=%d (C/4 must be a power of two, C <= 256)", C);
+  if (C > 256) {
+    gcl::set_error("gat: unsupported head width C=%d (C <= 256)", C);
     return GCL_EUNSUPPORTED;
   }
+  const int Cp = padded_width(C);
   int hc = 1;
-  while (hc * 2 <= H && hc * 2 * C <= 256) hc *= 2;
+  while (hc * 2 <= H && hc * 2 * Cp <= 256) hc *= 2;
   *chunk = hc;  // the last chunk(s) of a non-power-of-two H are smaller powers of two
   return GCL_OK;
 }
 inline int lpr_for(int heads, int C) {
-  const int lanes = heads * (C / 4);
+  const int lanes = heads * (padded_width(C) / 4);
   return lanes <= 4 ? 4 : lanes <= 8 ? 8 : lanes <= 16 ? 16 : lanes <= 32 ? 32 : 64;
 }
 // heads of the chunk that starts at h0
@@ -1177,7 +1211,7 @@ extern "C" int gcl_gat_fwd(const gcl_graph_t* g, const float* h, int64_t ldh, in
     if (nbs > 4096) nbs = 4096;
 #define CALL(L)                                                                                                     \
   hipLaunchKernelGGL((gat_scores_kernel<L>), dim3((unsigned)nbs), dim3(256), 0, st, hh, ldh, bsh, att_src + h0 * C, \
-                     att_dst + h0 * C, a_src, a_dst, g->n, B, hc, C, H, h0)
+                     att_dst + h0 * C, a_src, a_dst, g->n, B, hc, C, padded_width(C), H, h0)
     GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
     GCL_CHECK_LAUNCH();
@@ -1186,8 +1220,8 @@ extern "C" int gcl_gat_fwd(const gcl_graph_t* g, const float* h, int64_t ldh, in
     const int64_t nb = xcd_map ? (int64_t)8 * gcl::cdiv(B, 8) * nRB : (int64_t)B * nRB;
 #define CALL(L)                                                                                                       \
   hipLaunchKernelGGL((gat_fwd_kernel<L>), dim3((unsigned)nb), dim3(256), 0, st, g->rowptr, g->col, g->ecol, hh, ldh,  \
-                     bsh, a_src, a_dst, h0 == 0 ? bias : nullptr, alpha, y, ldy, bsy, g->n, g->e, B, hc, C, nRB,      \
-                     xcd_map, H, h0, H, h0 > 0 ? 1 : 0)
+                     bsh, a_src, a_dst, h0 == 0 ? bias : nullptr, alpha, y, ldy, bsy, g->n, g->e, B, hc, C,           \
+                     padded_width(C), nRB, xcd_map, H, h0, H, h0 > 0 ? 1 : 0)
     GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
     GCL_CHECK_LAUNCH();
@@ -1292,14 +1326,16 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
     if (!halo_done) {
 #define CALL(L)                                                                                                    \
   hipLaunchKernelGGL((gat_bwd_dst_kernel<L>), dim3(nb), dim3(256), 0, st, g->rowptr, g->col, g->ecol, dy, lddy,     \
-                     bsdy, hh, ldh, bsh, a_src, a_dst, alpha, de, dad, g->n, g->e, B, hc, C, nRB, xcd_map, H, h0, H)
+                     bsdy, hh, ldh, bsh, a_src, a_dst, alpha, de, dad, g->n, g->e, B, hc, C, padded_width(C), nRB,  \
+                     xcd_map, H, h0, H)
       GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
       GCL_CHECK_LAUNCH();
 #define CALL(L)                                                                                                       \
   hipLaunchKernelGGL((gat_bwd_src_kernel<L>), dim3(nb), dim3(256), 0, st, g->trowptr, g->tcol, g->tslot, g->tecol,    \
                      g->teslot, dy, lddy, bsdy, alpha, de, dad, att_src + h0 * C, att_dst + h0 * C, das,              \
-                     dh + (int64_t)h0 * C, lddh, bsdh, g->n, g->e, B, hc, C, nRB, vdy, xcd_map, H, h0, H)
+                     dh + (int64_t)h0 * C, lddh, bsdh, g->n, g->e, B, hc, C, padded_width(C), nRB, vdy, xcd_map, H,   \
+                     h0, H)
       GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
       GCL_CHECK_LAUNCH();
@@ -1311,7 +1347,7 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
     } else {
 #define CALL(L)                                                                                                    \
   hipLaunchKernelGGL((gat_datt_kernel<L>), dim3((unsigned)nbd), dim3(256), 0, st, hh, ldh, bsh, das, dad, part, g->n, \
-                     B, hc, C, H, h0)
+                     B, hc, C, padded_width(C), H, h0)
       GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
       GCL_CHECK_LAUNCH();

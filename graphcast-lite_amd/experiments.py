@@ -34,7 +34,7 @@ def _interaction_pipeline(F, steps, enc_hidden, dec_mlp_hidden, dec_mlp_out, dec
     }
 
 
-GRID = {"product_graph": (32, 64), "wb2_64x32_15f": (32, 64), "wb2_64x32_ar_15f_4obs_4pred": (32, 64), "demo_low": (32, 64),
+GRID = {"product_graph": (32, 64), "wb2_64x32_15f": (32, 64), "wb2_64x32_15f_gat": (32, 64), "wb2_64x32_ar_15f_4obs_4pred": (32, 64), "demo_low": (32, 64),
         "wb2_512x256_sparse_gat": (256, 512), "wb2_512x256_19f_ar_v2": (256, 512), "region_krsk_cds_19f": (32, 64), "baseline": (32, 64), "attention": (32, 64), "attention_h4": (32, 64), "sparse_attention": (32, 64),
         "wb2_512x256_19f_ar": (256, 512)}
 
@@ -57,8 +57,11 @@ def experiment(name: str, mesh_levels=None) -> ExperimentConfig:
         pipe = _pipeline([128, 128], 128, "conv_gcn", [128] * 4, [128, 64], 64, [64, 64], 19)
         graph.update(grid2mesh_radius_query=0.6, mesh_levels=mesh_levels or [4, 6])
         data.update(num_features_used=19)
-    elif name in ("wb2_64x32_15f", "wb2_64x32_ar_15f_4obs_4pred"):  # 4 observed steps, 96-wide GCN stacks
-        pipe = _pipeline([64, 64], 64, "conv_gcn", [96, 96, 96], [64, 64], 64, [48, 48], 15)
+    elif name in ("wb2_64x32_15f", "wb2_64x32_ar_15f_4obs_4pred", "wb2_64x32_15f_gat"):  # 4 observed steps, 96-wide stacks
+        # "_gat": the same widths with a GATConv processor (two heads of 96 channels: C / 4 = 24 is not a power of two)
+        gat = name.endswith("_gat")
+        pipe = _pipeline([64, 64], 64, "conv_gat" if gat else "conv_gcn", [96, 96, 96], [64, 64], 64, [48, 48], 15,
+                         **({"heads": 2} if gat else {}))
         pipe["encoder"]["gcn"].update(hidden_dims=[96, 96], output_dim=96)
         pipe["processor"]["gcn"].update(output_dim=96)
         graph.update(grid2mesh_radius_query=0.65, mesh_levels=mesh_levels or [4, 6])

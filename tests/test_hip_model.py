@@ -72,6 +72,7 @@ def data(cfg, G, B, seed=1234):
                                            ("region_krsk_cds_19f", [1, 2], 2), ("region_krsk_cds_19f", [2, 3], 1),
                                            ("wb2_512x256_19f_ar_v2", [1, 2], 1),
                                            ("wb2_64x32_15f", [1, 2], 2), ("wb2_64x32_15f", [4, 6], 1),
+                                           ("wb2_64x32_15f_gat", [1, 2], 2), ("wb2_64x32_15f_gat", [3, 5], 9),
                                            ("demo_low", [3], 3), ("product_graph", [1, 2], 2),
                                            ("product_graph", [1, 2], 1)])
 def test_forward_backward_parity(name, levels, B):

@@ -515,7 +515,12 @@ def test_colsum(hip, rows, F):
                                           # head counts the reference reports (README.md:148-150): 8 and 33 heads at C = 64
                                           # run as chunks of <= 4 heads; 3 and 6 heads exercise the uneven chunking
                                           ([1, 2], 8, 64, 2), ([1, 2], 33, 64, 2), ([3, 5], 8, 64, 9), ([0], 3, 64, 1),
-                                          ([1, 2], 6, 32, 2)])
+                                          ([1, 2], 6, 32, 2),
+                                          # head widths whose C / 4 is not a power of two (the reference's GATConv takes any
+                                          # hidden width, src/models.py:332-358; 96 is the wb2_64x32_15f stack width): a head
+                                          # is padded to the next power-of-two lane count, its idle lanes contribute zeros
+                                          ([1, 2], 1, 48, 3), ([1, 2], 2, 96, 2), ([1, 2], 3, 48, 2), ([3, 5], 1, 96, 9),
+                                          ([0], 5, 20, 1), ([1, 2], 1, 12, 2), ([1, 2], 4, 36, 2)])
 def test_gat_fwd_bwd(hip, levels, H, C, B):
     g = build_graphs(experiment("baseline", mesh_levels=levels))
     n = g["M"]
@@ -617,10 +622,13 @@ def test_gat_fwd_source_tiles(hip, levels, C, B, monkeypatch):
 def test_gat_unsupported_geometry_is_reported(hip):
     g = build_graphs(experiment("baseline", mesh_levels=[0]))
     G = hip.Graph(g["proc"], 12, hip.GRAPH_GAT)
-    h = torch.zeros(1, 12, 2 * 48, device=DEV)
-    z = torch.zeros(2 * 48, device=DEV)
-    with pytest.raises(RuntimeError, match="unsupported head width"):  # C / 4 = 12 is not a power of two
-        hip.gat_fwd(G, h, z, z, torch.zeros(48, device=DEV), 2, 48)
+    h = torch.zeros(1, 12, 260, device=DEV)
+    z = torch.zeros(260, device=DEV)
+    with pytest.raises(RuntimeError, match="unsupported head width"):  # one head must fit the 64 lanes x 4 channels of a wave
+        hip.gat_fwd(G, h, z, z, torch.zeros(260, device=DEV), 1, 260)
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        hip.gat_fwd(G, torch.zeros(1, 12, 36, device=DEV), torch.zeros(34, device=DEV), torch.zeros(34, device=DEV),
+                    torch.zeros(34, device=DEV), 1, 34)
 
 
 def test_gat_prune(hip):
