@@ -39,10 +39,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, in
   const int n = (int)(nbytes < 0 ? 0 : (nbytes > cap ? cap : nbytes));
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
 }
+template <int AUX = 0>  // cache-policy bits: 2 = non-temporal
 __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v) {
   u32x4 u = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z),
              __builtin_bit_cast(unsigned, v.w)};
-  __builtin_amdgcn_raw_buffer_store_b128(u, r, off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, off, 0, AUX);
 }
 __device__ float4 gl_zero4[1];
 
@@ -452,7 +453,7 @@ __device__ __forceinline__ void mfma_tile_x3(f32x16 (&acc)[NS], const float* __r
 
 // Transpose the 32 x (NS*32) accumulator tile through the wave's LDS region Ot[32][NS*32] and write whole
 // 16-byte row segments:  Y[r0 + i][0 .. Nst) (rows >= nr and columns >= Nst dropped by the range check).
-template <int NS>
+template <int NS, int AUX = 0>
 __device__ __forceinline__ void store_tile(const f32x16 (&acc)[NS], float* __restrict__ Ot, float* Ybase, int64_t ldy,
                                            int nr, int Nst, float4 bq = make_float4(0.f, 0.f, 0.f, 0.f)) {
   constexpr int OS = NS * 32;          // floats per staged row
@@ -470,7 +471,7 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[NS], float* __res
     const int i = p * RPP + orow;
     float4 v = *reinterpret_cast<const float4*>(Ot + i * OS + ocol);
     v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;  // (zero unless the bias was kept out of the accumulator)
-    buf_st4(ry, (ocol < Nst) ? (unsigned)((i * ldy + ocol) * 4) : kOOB, v);
+    buf_st4<AUX>(ry, (ocol < Nst) ? (unsigned)((i * ldy + ocol) * 4) : kOOB, v);
   }
 }
 
@@ -593,8 +594,8 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void gcn_fwd_kernel(
 // mesh graph (145 us per layer against 61 us for the source-tile aggregation of the same rows).
 // Block = 4 waves, persistent over a contiguous range of (tile, sample) items, tile-major (list entries and edge
 // records of a tile stay in registers for all samples of the XCD group).  Per item:
-//   wait DMA + barrier | sums of the wave's 16 rows (row_fma<ACT>, CSR order: the arithmetic of gather_tile above, bit
-//   for bit) -> At[pair][32][KP] | barrier (At complete, image free) | DMA of the NEXT item (inline asm: in flight
+//   wait DMA | act(x) in place on the pieces the wave's own DMAs delivered | barrier | sums of the wave's 16 rows (fused
+//   multiply-adds in CSR order: gather_tile's arithmetic on a pre-activated input, bit for bit) -> At[pair][32][KP] | barrier (At complete, image free) | DMA of the NEXT item (inline asm: in flight
 //   under what follows) | wave (pair p, half h): acc = At[p] x W[h*32 .. +31]^T on the bf16 pipe (x3) | barrier |
 //   transpose through At[p]'s half h, 16-byte row stores.
 // The wave's weight fragments (all pieces, all k-steps) live in registers, so LDS holds only At (16.9 KB) and the
@@ -626,7 +627,15 @@ __device__ __forceinline__ WFrag load_wfrag(const float* __restrict__ W, int j0,
   return wf;
 }
 
-__device__ __forceinline__ void mfma_half_x3(f32x16& acc, const float* __restrict__ At, int KP, const WFrag& wf, int nks) {
+struct NoBetween {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+// `between(s)` runs after the operands of k-step s are split (the source-tile kernel issues two LDS-DMA pieces of the
+// next item there: a DMA instruction that waits for a free slot in the memory pipeline then overlaps the splits and
+// the matrix chain of the same wave instead of standing in front of them)
+template <class F = NoBetween>
+__device__ __forceinline__ void mfma_half_x3(f32x16& acc, const float* __restrict__ At, int KP, const WFrag& wf, int nks,
+                                             F between = F()) {
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const float* ap = At + r * KP + 8 * h;
   bf16x8 ah[4], am[4], al[4];
@@ -641,6 +650,7 @@ __device__ __forceinline__ void mfma_half_x3(f32x16& acc, const float* __restric
       am[s] = __builtin_bit_cast(bf16x8, u32x4_t{p0.m, p1.m, p2.m, p3.m});
       al[s] = __builtin_bit_cast(bf16x8, u32x4_t{p0.l, p1.l, p2.l, p3.l});
     }
+    between(s);
   }
   // the order of mfma_tile_x3 (smallest products first), so both kernels produce the same bits
 #pragma unroll
@@ -661,7 +671,7 @@ __device__ __forceinline__ void mfma_half_x3(f32x16& acc, const float* __restric
     if (s < nks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], wf.f[s][0], acc, 0, 0, 0);
 }
 
-template <int ACT, int MAXPW>
+template <int ACT, int MAXPW, int STAUX = 0, bool DIRECT = false, bool INTER = false>
 __global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
     const int32_t* __restrict__ list, const int32_t* __restrict__ cnt, const int2* __restrict__ rec,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ opos, const float* __restrict__ w, int32_t smax,
@@ -698,7 +708,9 @@ __global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
     bq.x = oc < N ? bias[oc] : 0.f; bq.y = oc + 1 < N ? bias[oc + 1] : 0.f;
     bq.z = oc + 2 < N ? bias[oc + 2] : 0.f; bq.w = oc + 3 < N ? bias[oc + 3] : 0.f;
   }
-  asm volatile("" : "+v"(bq.x), "+v"(bq.y), "+v"(bq.z), "+v"(bq.w));  // hipcc's wait for these loads: here, not in the loop
+  float bcol = 0.f;  // DIRECT: bias of the ONE output column this lane's accumulator registers belong to
+  if (bias && half * 32 + (lane & 31) < N) bcol = bias[half * 32 + (lane & 31)];
+  asm volatile("" : "+v"(bq.x), "+v"(bq.y), "+v"(bq.z), "+v"(bq.w), "+v"(bcol));  // hipcc's wait for these loads: here, not in the loop
   __syncthreads();
 
   const int xcd = blockIdx.x & (gcl::kNumXCD - 1);
@@ -747,6 +759,21 @@ __global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
       if (p < nhalo) glds16(Xc, __umul24(jj[q], ldb) + cb, lds_img + (unsigned)((T + p * RPW) << SH));
     }
   };
+  // INTER: the same pieces two at a time, piece index 0..3 = own rows, 4.. = halo
+  const char* Xn = nullptr;
+  auto stage_pair = [&](int s2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pc = s2 * 2 + u;
+      if (pc < NIT) {
+        const int row = tile * T + wave * 16 + sub + pc * RPW;
+        glds16(Xn, __umul24(row < n ? row : n - 1, ldb) + cb, lds_img + (unsigned)((wave * 16 + pc * RPW) << SH));
+      } else if (pc - NIT < MAXPW) {
+        const int q = pc - NIT, p = wave + 4 * q;
+        if (p < nhalo) glds16(Xn, __umul24(jj[q < MAXPW ? q : 0], ldb) + cb, lds_img + (unsigned)((T + p * RPW) << SH));
+      }
+    }
+  };
   new_tile(m / nsamp);
 #pragma unroll
   for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(rc[it].x), "+v"(rc[it].y));  // records are in before any DMA is issued
@@ -760,6 +787,31 @@ __global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
     const int b = xcd + gcl::kNumXCD * s;
     const int trow = tile * T;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the item (and its stores of the previous one)
+    if (ACT != gcl::kActNone) {
+      // the input activation ONCE per staged element, in place, by the lane whose DMA delivered the piece (no other wave
+      // has touched the image yet): the sums then weigh act(x) like plain rows.  A row is read by 7.4 edges on the mesh,
+      // so activating per edge (gather_tile's row_fma<ACT>) cost 10 extra vector instructions per slot and lane.
+      typedef __attribute__((address_space(3))) v4f* lds4w_t;
+      auto act_piece = [&](unsigned ad) {
+        v4f v = *(lds4_t)ad;
+        if (ACT == gcl::kActPrelu) {
+          v.x = v.x > 0.f ? v.x : slope * v.x; v.y = v.y > 0.f ? v.y : slope * v.y;
+          v.z = v.z > 0.f ? v.z : slope * v.z; v.w = v.w > 0.f ? v.w : slope * v.w;
+        } else {
+          v.x = gcl::silu_f(v.x); v.y = gcl::silu_f(v.y); v.z = gcl::silu_f(v.z); v.w = gcl::silu_f(v.w);
+        }
+        *(lds4w_t)ad = v;
+      };
+      const unsigned la = lds_img + (unsigned)lane * 16u;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) act_piece(la + (unsigned)((wave * 16 + it * RPW) << SH));
+#pragma unroll
+      for (int q = 0; q < MAXPW; ++q) {
+        const int p = wave + 4 * q;
+        if (p < nhalo) act_piece(la + (unsigned)((T + p * RPW) << SH));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                       // image complete
     GCL_STAMP(0);  // wait for the item + barrier
     // ---- sums of this wave's 16 rows: a = sum_e w_e act(x_src), CSR order, fused multiply-adds (row_fma)
@@ -775,7 +827,7 @@ __global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
     const unsigned ad = (unsigned)row_bcast<Kk>(rxb) + lb;              \
     const float wk = __int_as_float(row_bcast<Kk>(rw));                 \
     const v4f v = *(lds4_t)ad;                                          \
-    row_fma<ACT>(a01, a23, make_float4(v.x, v.y, v.z, v.w), wk, slope); \
+    row_fma<gcl::kActNone>(a01, a23, make_float4(v.x, v.y, v.z, v.w), wk, 1.f); \
   }
       GCL_FUSED_SLOT(0) GCL_FUSED_SLOT(1) GCL_FUSED_SLOT(2) GCL_FUSED_SLOT(3)
       GCL_FUSED_SLOT(4) GCL_FUSED_SLOT(5) GCL_FUSED_SLOT(6) GCL_FUSED_SLOT(7)
@@ -788,7 +840,7 @@ __global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
           const int end = (last & gcl::kHaloMore) ? rowptr[rcl + 1] : 0;
           for (int e = rowptr[rcl] + gcl::kHaloRec; e < end; ++e) {
             const v4f v = *(lds4_t)(((unsigned)opos[e] << SH) + lb);
-            row_fma<ACT>(a01, a23, make_float4(v.x, v.y, v.z, v.w), w[e], slope);
+            row_fma<gcl::kActNone>(a01, a23, make_float4(v.x, v.y, v.z, v.w), w[e], 1.f);
           }
         }
       }
@@ -808,18 +860,43 @@ __global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
     if (more) {
       const int tn = (m + 1) / nsamp;
       if (tn != tile) new_tile(tn);
-      stage(m + 1);
+      if (!INTER) stage(m + 1);
+      else Xn = reinterpret_cast<const char*>(X + (int64_t)(xcd + gcl::kNumXCD * (m + 1 - tile * nsamp)) * bsx);
     }
     GCL_STAMP(3);  // DMA issue of the next item
     // ---- dense part: wave (pair, half) = rows [pair*32, +32) x output columns [half*32, +32)
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (INTER) {
+      static_assert(!INTER || NIT + MAXPW <= 8, "the interleaved issue places two pieces behind each of four k-steps");
+      mfma_half_x3(acc, Ap, KP, wf, K >> 4, [&](int s2) {  // four callback slots whatever K is (K = 48: slot 3 has no k-step)
+        if (more) stage_pair(s2);
+      });
+    } else
     mfma_half_x3(acc, Ap, KP, wf, K >> 4);
 #ifdef GCL_STAMPS
     asm volatile("" ::"v"(acc[0]));
 #endif
     GCL_STAMP(4);  // split + MFMA
+    if (DIRECT) {
+      // straight from the accumulator: register r of lane L is element (d_row(r, L), L & 31) of the 32 x 32 block, so one
+      // store instruction writes two rows x 32 consecutive columns = two whole 128-byte lines - no staging tile, no
+      // third barrier (the next item's sums cannot touch At before every wave has passed the next barrier 1)
+      const int r0 = trow + pair * 32;
+      const int nr = n - r0 < 32 ? n - r0 : 32;
+      const int col = half * 32 + (lane & 31);
+      float* Yb = Y + (int64_t)b * bsy + (int64_t)r0 * ldy;
+      const __amdgpu_buffer_rsrc_t ry = make_rsrc(Yb, nr > 0 ? ((int64_t)(nr - 1) * ldy + Nst) * 4 : 0);
+      const unsigned cofs = col < Nst ? (unsigned)col * 4u : kOOB;
+      const unsigned ldyb = (unsigned)ldy * 4u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned off = (unsigned)d_row(r, lane) * ldyb + cofs;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[r] + bcol), ry, off, 0, STAUX);
+      }
+      GCL_STAMP(6);
+    } else {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // both waves of the pair have read At[pair]: its halves become the output staging
     GCL_STAMP(5);  // barrier
@@ -829,9 +906,10 @@ __global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
       const int nr = n - r0 < 32 ? n - r0 : 32;
       int nst = Nst - half * 32;
       nst = nst < 0 ? 0 : (nst > 32 ? 32 : nst);
-      store_tile<1>(accv, Ap + half * (32 * 32), Y + (int64_t)b * bsy + (int64_t)r0 * ldy + half * 32, ldy, nr, nst, bq);
+      store_tile<1, STAUX>(accv, Ap + half * (32 * 32), Y + (int64_t)b * bsy + (int64_t)r0 * ldy + half * 32, ldy, nr, nst, bq);
     }
     GCL_STAMP(6);  // transpose + stores
+    }
 #ifdef GCL_STAMPS
     stamp_acc[7] += 1;
 #endif
@@ -914,9 +992,22 @@ extern "C" int gcl_gcn_layer_fwd_rows(const gcl_graph_t* g, const float* x, int6
         return GCL_OK;
       };
       int rc;
-      if (act == GCL_ACT_PRELU) rc = hp4 <= 4 ? go(&gcn_halo_fwd_kernel<gcl::kActPrelu, 4>) : go(&gcn_halo_fwd_kernel<gcl::kActPrelu, 8>);
-      else if (act == GCL_ACT_SILU) rc = hp4 <= 4 ? go(&gcn_halo_fwd_kernel<gcl::kActSilu, 4>) : go(&gcn_halo_fwd_kernel<gcl::kActSilu, 8>);
-      else rc = hp4 <= 4 ? go(&gcn_halo_fwd_kernel<gcl::kActNone, 4>) : go(&gcn_halo_fwd_kernel<gcl::kActNone, 8>);
+      // hp4 <= 4 (the icosphere meshes: <= 64 halo rows per tile): non-temporal stores straight from the accumulator and
+      // the next item's DMA pieces issued between the k-steps of the dense part (in the step 111.5 -> 102.6 us per mesh
+      // layer; GCL_GCN_HALO_FORM=0 selects the first form - DMA issue up front, staged 16-byte stores - for comparison)
+      static const int form_env = env_int("GCL_GCN_HALO_FORM", 1);
+      if (hp4 <= 4 && form_env)
+        rc = act == GCL_ACT_PRELU  ? go(&gcn_halo_fwd_kernel<gcl::kActPrelu, 4, 2, true, true>)
+             : act == GCL_ACT_SILU ? go(&gcn_halo_fwd_kernel<gcl::kActSilu, 4, 2, true, true>)
+                                   : go(&gcn_halo_fwd_kernel<gcl::kActNone, 4, 2, true, true>);
+      else if (hp4 <= 4)
+        rc = act == GCL_ACT_PRELU  ? go(&gcn_halo_fwd_kernel<gcl::kActPrelu, 4>)
+             : act == GCL_ACT_SILU ? go(&gcn_halo_fwd_kernel<gcl::kActSilu, 4>)
+                                   : go(&gcn_halo_fwd_kernel<gcl::kActNone, 4>);
+      else
+        rc = act == GCL_ACT_PRELU  ? go(&gcn_halo_fwd_kernel<gcl::kActPrelu, 8, 2, true>)
+             : act == GCL_ACT_SILU ? go(&gcn_halo_fwd_kernel<gcl::kActSilu, 8, 2, true>)
+                                   : go(&gcn_halo_fwd_kernel<gcl::kActNone, 8, 2, true>);
       if (rc) return rc;
       GCL_CHECK_LAUNCH();
       return GCL_OK;

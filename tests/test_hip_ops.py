@@ -867,11 +867,21 @@ def test_gcn_layer_fwd_source_tiles(hip, levels, Fin, Fout, B, act, monkeypatch)
     xa = _act_ref(x, act, a)
     ref = torch.stack([P.gcn_conv(xa[i], g["proc"], W, b) for i in range(min(B, 3))])
     outs = {}
+    xd = x[:, order].contiguous().to(DEV)
+    sl = a.to(DEV) if act == 1 else None
     for mode in ("1", "0"):
         monkeypatch.setenv("GCL_GCN_HALO", mode)
-        outs[mode] = hip.gcn_layer_fwd(gh, x[:, order].contiguous().to(DEV), act, a.to(DEV) if act == 1 else None, W.to(DEV),
-                                       b.to(DEV)).cpu()
-    assert torch.equal(outs["1"], outs["0"]), "source-tile layer and per-edge layer differ in some bit"
+        outs[mode] = hip.gcn_layer_fwd(gh, xd, act, sl, W.to(DEV), b.to(DEV)).cpu()
+    if act == hip.ACT_NONE:
+        assert torch.equal(outs["1"], outs["0"]), "source-tile layer and per-edge layer differ in some bit"
+    else:
+        # the staged form activates every staged element ONCE in the LDS image (exactly x > 0 ? x : a x, or the device's
+        # SiLU) and then runs the plain sums: bit-equal to the per-edge layer WITHOUT activation on a materialised act(x);
+        # the per-edge layer with its own per-edge activation (a w x + (1 - a) w relu(x)) rounds differently
+        monkeypatch.setenv("GCL_GCN_HALO", "0")
+        pre = hip.gcn_layer_fwd(gh, hip.act_fwd(xd, act, sl), hip.ACT_NONE, None, W.to(DEV), b.to(DEV)).cpu()
+        assert torch.equal(outs["1"], pre), "source-tile layer differs in some bit from the per-edge layer on act(x)"
+        assert rel(outs["1"], outs["0"]) < 2e-6
     assert rel(outs["1"][: min(B, 3), pos], ref) < TOL
 
 
@@ -894,17 +904,23 @@ def test_x3_wide_contractions_exact_on_integers(hip, rows, Fin, Fout):
     assert torch.equal(dgot.cpu(), dref), f"dX differs in {(dgot.cpu() != dref).sum().item()} elements"
 
 
-@pytest.mark.parametrize("n,Fin,Fout,B", [(64 * 9 + 5, 64, 64, 3), (300, 48, 33, 2), (2000, 64, 19, 5)])
-def test_x3_gcn_layer_exact_on_integers(hip, n, Fin, Fout, B, monkeypatch):
+@pytest.mark.parametrize("n,Fin,Fout,B,wide", [(64 * 9 + 5, 64, 64, 3, False), (300, 48, 33, 2, False), (2000, 64, 19, 5, False),
+                                               # neighbours up to 40 rows away: 80 halo rows per 64-row tile, the staged
+                                               # kernel's eight-piece halo variant (the icosphere meshes need <= 64)
+                                               (64 * 7 + 11, 64, 64, 9, True), (700, 48, 33, 2, True)])
+def test_x3_gcn_layer_exact_on_integers(hip, n, Fin, Fout, B, wide, monkeypatch):
     """The one-kernel GCNConv layer with the dense part on the bf16 pipe (gcn_fwd_kernel<.., X3> and, where the graph
     carries a source-tile layout, gcn_halo_fwd_kernel): a ring in which every node has exactly sixteen in-edges (fifteen
     neighbours + its self-loop) gives every edge the weight 1/sqrt(16) * 1/sqrt(16) = 1/16, so with small-integer x and
     W the aggregated tile, every piece product and every partial sum are exact: the layer must be BIT-equal to float64
     (the sixteen edges also walk both halves of the staged form's edge records)."""
     idx = torch.arange(n)
-    offs = [d for d in range(-7, 9) if d != 0]
+    offs = [-40, -33, -25, -18, -12, -7, -3, -1, 1, 2, 5, 9, 14, 22, 31] if wide else [d for d in range(-7, 9) if d != 0]
     ei = torch.stack([torch.cat([(idx + d) % n for d in offs]), idx.repeat(len(offs))])
     gh = hip.Graph(ei, n, hip.GRAPH_GCN)
+    if wide:
+        info = gh.halo_info(False, 64)
+        assert info is not None and info[2] - 64 > 64, f"expected more than 64 halo rows per tile, got {info}"
     g = torch.Generator().manual_seed(13)
     x = torch.randint(-7, 8, (B, n, Fin), generator=g).float()
     W = torch.randint(-5, 6, (Fout, Fin), generator=g).float()

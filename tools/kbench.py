@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--config", default="baseline")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--ring", type=int, default=1, help="rotate the aggregation / layer launches over this many distinct input and "
+                    "output buffers (>= 3 at cfg A keeps the 256 MB Infinity Cache from serving a repeated launch its own previous input)")
     ap.add_argument("--only", default="", help="comma list of: copy,linear,agg,gcn,gat,norm,misc (default all but gat)")
     args = ap.parse_args()
     name = "wb2_512x256_19f_ar" if args.config.startswith("wb2") else args.config
@@ -89,22 +91,30 @@ def main():
     from graphcast_lite_amd.models import _graphs
     for ei, nn_, tag in () if "agg" not in only else ((m.processor_graph(), M, "mesh E_M (tile order)"), (m.encoding_graph, n, "enc E_G2M"), (m.decoding_graph, n, "dec E_M2G")):
         gr = _graphs.get(ei, nn_, hip.GRAPH_GCN)
-        h, bias = rnd(B, nn_, F), rnd(F)
-        out = torch.empty(B, nn_, F, device=dev)
+        bias = rnd(F)
+        hs, outs, k = [rnd(B, nn_, F) for _ in range(args.ring)], [torch.empty(B, nn_, F, device=dev) for _ in range(args.ring)], [0]
+
+        def agg(transpose):
+            k[0] = (k[0] + 1) % args.ring
+            hip.aggregate(gr, hs[k[0]], None if transpose else bias, transpose=transpose, out=outs[k[0]])
         per = 4 * nn_ * 2 * F + 4 * gr.e + 4 * (nn_ + 1) + 4 * nn_
-        us, mn = timeit(lambda: hip.aggregate(gr, h, bias, out=out), args.iters)
+        us, mn = timeit(lambda: agg(False), args.iters)
         row(f"aggregate fwd {tag} n={nn_} E'={gr.e} F={F}", us, mn, B * per, 2 * B * gr.e * F)
-        us, mn = timeit(lambda: hip.aggregate(gr, h, None, transpose=True, out=out), args.iters)
+        us, mn = timeit(lambda: agg(True), args.iters)
         row(f"aggregate bwd {tag} (transpose)", us, mn, B * per, 2 * B * gr.e * F)
 
     # one-kernel GCNConv layer (aggregate-first): the same per-layer algorithmic bytes as the aggregation
     for ei, nn_, tag in () if "gcn" not in only else ((m.processor_graph(), M, "mesh E_M (tile order)"), (m.encoding_graph, n, "enc E_G2M"), (m.decoding_graph, n, "dec E_M2G")):
         gr = _graphs.get(ei, nn_, hip.GRAPH_GCN)
-        x, W, bias = rnd(B, nn_, F), rnd(F, F) * 0.1, rnd(F)
-        out = torch.empty(B, nn_, F, device=dev)
+        W, bias = rnd(F, F) * 0.1, rnd(F)
+        xs, outs, k = [rnd(B, nn_, F) for _ in range(args.ring)], [torch.empty(B, nn_, F, device=dev) for _ in range(args.ring)], [0]
+
+        def layer(act):
+            k[0] = (k[0] + 1) % args.ring
+            hip.gcn_layer_fwd(gr, xs[k[0]], act, slope if act else None, W, bias, out=outs[k[0]])
         per = 4 * nn_ * 2 * F + 4 * gr.e + 4 * (nn_ + 1) + 4 * nn_
         for act, an in ((hip.ACT_NONE, "none"), (hip.ACT_PRELU, "prelu")):
-            us, mn = timeit(lambda: hip.gcn_layer_fwd(gr, x, act, slope if act else None, W, bias, out=out), args.iters)
+            us, mn = timeit(lambda: layer(act), args.iters)
             row(f"gcn_layer_fwd {tag} act={an} F={F}", us, mn, B * per, 2 * B * nn_ * F * F + 2 * B * gr.e * F)
 
     # GATConv / SparseGATConv attention aggregation on the mesh graph (H = 1 head of C = F channels, as configs[2]/[4])
