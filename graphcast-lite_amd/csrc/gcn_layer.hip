@@ -671,13 +671,18 @@ __device__ __forceinline__ void mfma_half_x3(f32x16& acc, const float* __restric
     if (s < nks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], wf.f[s][0], acc, 0, 0, 0);
 }
 
-template <int ACT, int MAXPW, int STAUX = 0, bool DIRECT = false, bool INTER = false>
+// TAB: the layer's input rows are read THROUGH a row table instead of from a materialised [B, n, K] tensor: row i of
+// sample b is row tab[i] of sample b of X when tab[i] >= 0, and the batch-invariant row ~tab[i] of X viewed as one flat
+// row list otherwise (the compact pipeline's mesh latents: models.py::_forward_compact, functional.MeshLatFn - 81 % of
+// the mesh rows at 64x32 are batch-invariant and then come from a 2 MB region that stays in the L2).  The table is
+// applied once per tile (list entries and own rows), so an item costs two more vector instructions per DMA piece.
+template <int ACT, int MAXPW, int STAUX = 0, bool DIRECT = false, bool INTER = false, bool TAB = false>
 __global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
     const int32_t* __restrict__ list, const int32_t* __restrict__ cnt, const int2* __restrict__ rec,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ opos, const float* __restrict__ w, int32_t smax,
     const float* __restrict__ X, int64_t ldx, int64_t bsx, const float* __restrict__ slope_p, const float* __restrict__ W,
     const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy, int64_t bsy, int32_t n, int32_t B, int32_t K,
-    int32_t N, int32_t Nst, int32_t ntiles) {
+    int32_t N, int32_t Nst, int32_t ntiles, const int32_t* __restrict__ tab = nullptr) {
   using gcl::halo::glds16;
   using gcl::halo::row_bcast;
   extern __shared__ __align__(16) float smem[];
@@ -723,6 +728,7 @@ __global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
   if (m >= mend) return;
 
   int jj[MAXPW], nhalo = 0, tile = -1;
+  int own[TAB ? NIT : 1];  // TAB: table entries of the wave's own rows
   int2 rc[NIT];
   auto new_tile = [&](int t) {  // list entries (scalar loads) and edge records of tile t: kept for all samples of the group
     tile = t;
@@ -737,46 +743,58 @@ __global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
         const int jr = tl[e0 + r];
         jv = sub == r ? jr : jv;
       }
-      jj[q] = jv;
+      jj[q] = TAB ? tab[jv] : jv;
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int row = t * T + wave * 16 + sub + it * RPW;
       rc[it] = rec[(int64_t)(row < n ? row : n - 1) * gcl::kHaloRec + l];
+      if (TAB) own[it] = tab[row < n ? row : n - 1];
     }
+  };
+  // byte offset of a staged source row: plain row id (relative to the sample's base) or table entry (relative to X)
+  auto src_off = [&](int src, unsigned sboff) -> unsigned {
+    if (!TAB) return __umul24(src, ldb) + cb;
+    return (src >= 0 ? sboff + __umul24(src, ldb) : __umul24(~src, ldb)) + cb;
   };
   auto stage = [&](int mm) {  // all DMA pieces of item mm (its tile is `tile`)
     const int s = mm - tile * nsamp;
-    const char* Xc = reinterpret_cast<const char*>(X + (int64_t)(xcd + gcl::kNumXCD * s) * bsx);
+    const char* Xc = reinterpret_cast<const char*>(X + (TAB ? 0 : (int64_t)(xcd + gcl::kNumXCD * s) * bsx));
+    const unsigned sboff = TAB ? (unsigned)(xcd + gcl::kNumXCD * s) * (unsigned)bsx * 4u : 0u;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int row = tile * T + wave * 16 + sub + it * RPW;
-      glds16(Xc, __umul24(row < n ? row : n - 1, ldb) + cb, lds_img + (unsigned)((wave * 16 + it * RPW) << SH));
+      glds16(Xc, src_off(TAB ? own[TAB ? it : 0] : (row < n ? row : n - 1), sboff), lds_img + (unsigned)((wave * 16 + it * RPW) << SH));
     }
 #pragma unroll
     for (int q = 0; q < MAXPW; ++q) {
       const int p = wave + 4 * q;
-      if (p < nhalo) glds16(Xc, __umul24(jj[q], ldb) + cb, lds_img + (unsigned)((T + p * RPW) << SH));
+      if (p < nhalo) glds16(Xc, src_off(jj[q], sboff), lds_img + (unsigned)((T + p * RPW) << SH));
     }
   };
   // INTER: the same pieces two at a time, piece index 0..3 = own rows, 4.. = halo
   const char* Xn = nullptr;
+  unsigned sbn = 0;
   auto stage_pair = [&](int s2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int pc = s2 * 2 + u;
       if (pc < NIT) {
         const int row = tile * T + wave * 16 + sub + pc * RPW;
-        glds16(Xn, __umul24(row < n ? row : n - 1, ldb) + cb, lds_img + (unsigned)((wave * 16 + pc * RPW) << SH));
+        glds16(Xn, src_off(TAB ? own[TAB ? pc : 0] : (row < n ? row : n - 1), sbn), lds_img + (unsigned)((wave * 16 + pc * RPW) << SH));
       } else if (pc - NIT < MAXPW) {
         const int q = pc - NIT, p = wave + 4 * q;
-        if (p < nhalo) glds16(Xn, __umul24(jj[q < MAXPW ? q : 0], ldb) + cb, lds_img + (unsigned)((T + p * RPW) << SH));
+        if (p < nhalo) glds16(Xn, src_off(jj[q < MAXPW ? q : 0], sbn), lds_img + (unsigned)((T + p * RPW) << SH));
       }
     }
   };
   new_tile(m / nsamp);
 #pragma unroll
   for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(rc[it].x), "+v"(rc[it].y));  // records are in before any DMA is issued
+  if (TAB) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(own[TAB ? it : 0]));
+  }
   stage(m);
 #ifdef GCL_STAMPS
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
@@ -861,6 +879,7 @@ __global__ __launch_bounds__(256, 3) void gcn_halo_fwd_kernel(
       const int tn = (m + 1) / nsamp;
       if (tn != tile) new_tile(tn);
       if (!INTER) stage(m + 1);
+      else if (TAB) Xn = reinterpret_cast<const char*>(X), sbn = (unsigned)(xcd + gcl::kNumXCD * (m + 1 - tile * nsamp)) * (unsigned)bsx * 4u;
       else Xn = reinterpret_cast<const char*>(X + (int64_t)(xcd + gcl::kNumXCD * (m + 1 - tile * nsamp)) * bsx);
     }
     GCL_STAMP(3);  // DMA issue of the next item
@@ -938,6 +957,70 @@ extern "C" int gcl_debug_read_stamps(unsigned long long* host_out, int count) {
 }
 #endif
 
+// Source-tile form of the layer (gcn_halo_fwd_kernel): graphs with a tile layout (mesh rows in tile order), 64-wide rows,
+// split-operand dense part.  Returns GCL_OK with *launched = false when the shape / graph is outside its range.
+// tab != nullptr: the input rows are read through the row table (see the kernel), x_rows = rows of X as one flat list.
+static int halo_layer_launch(const gcl_graph_t* g, const float* x, int64_t ldx, int64_t bsx, const int32_t* tab,
+                             int64_t x_rows, int32_t act, const float* slope, const float* W, const float* bias, float* y,
+                             int64_t ldy, int64_t bsy, int32_t B, int32_t Fin, int32_t Fout, int32_t Fout_store,
+                             int32_t rows_out, hipStream_t st, bool* launched) {
+  *launched = false;
+  const int32_t n = g->n;
+  const int halo_on = env_int("GCL_GCN_HALO", 1);  // read per call: the parity test compares the two kernels
+  static const int x3_on = env_int("GCL_X3", 1) && env_int("GCL_X3_GCN", 1);
+  const gcl_halo& hl = g->halo[0][0];
+  const int hp4 = hl.T == 64 ? (int)gcl::cdiv((hl.smax - 64) / 4, 4) : 99;
+  const int KPh = Fin + 2;
+  const size_t ldsh = (size_t)2 * (32 * KPh > 2048 ? 32 * KPh : 2048) * 4 + (size_t)(hl.smax + 1) * 256;
+  // 32-bit byte offsets: inside one sample without a table, inside the whole of X with one
+  const bool offs_ok = tab ? (x_rows * ldx * 4 < ((int64_t)1 << 32) && (int64_t)B * bsx * 4 < ((int64_t)1 << 32) && x_rows < (1 << 24))
+                           : ((int64_t)n * ldx * 4 < ((int64_t)1 << 31));
+  // only where the gather is the bulk of the layer (>= 6 edges per row: the mesh graph has 7.4): on the decoder graph
+  // of the 512x256 configs (3.3 edges per row) the per-edge kernel's twelve wave-independent pipelines run 1.6x faster
+  if (!(halo_on && x3_on && g->kind == GCL_GRAPH_GCN && hl.T == 64 && hp4 <= 8 && Fin % 16 == 0 && Fin > 32 && rows_out == n &&
+        g->e >= 6 * (int64_t)n && ldsh <= 80 * 1024 && offs_ok && n < (1 << 24) && ldx * 4 < (1 << 24) &&
+        (int64_t)n * ldy * 4 < ((int64_t)1 << 31)))
+    return GCL_OK;
+  if (tab && hp4 > 4) return GCL_OK;  // the table variant exists for the interleaved-issue form only
+  static const int bpc_env = env_int("GCL_GCN_HALO_BPC", 0);
+  const int per_cu = (int)((160 * 1024) / ldsh);
+  const int Jx = 32 * (bpc_env > 0 ? bpc_env : per_cu);
+  dim3 grid((unsigned)(gcl::kNumXCD * Jx));
+  auto go = [&](auto kern) -> int {
+    const int rc = gcl::ensure_dyn_lds((const void*)kern, ldsh);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(256), ldsh, st, hl.list, hl.cnt, reinterpret_cast<const int2*>(hl.rec), g->rowptr,
+                       hl.opos, g->w, hl.smax, x, ldx, bsx, slope, W, bias, y, ldy, bsy, n, B, Fin, Fout, Fout_store,
+                       hl.ntiles, tab);
+    return GCL_OK;
+  };
+  int rc;
+  // hp4 <= 4 (the icosphere meshes: <= 64 halo rows per tile): non-temporal stores straight from the accumulator and
+  // the next item's DMA pieces issued between the k-steps of the dense part (in the step 111.5 -> 102.6 us per mesh
+  // layer; GCL_GCN_HALO_FORM=0 selects the first form - DMA issue up front, staged 16-byte stores - for comparison)
+  static const int form_env = env_int("GCL_GCN_HALO_FORM", 1);
+  if (tab)
+    rc = act == GCL_ACT_PRELU  ? go(&gcn_halo_fwd_kernel<gcl::kActPrelu, 4, 2, true, true, true>)
+         : act == GCL_ACT_SILU ? go(&gcn_halo_fwd_kernel<gcl::kActSilu, 4, 2, true, true, true>)
+                               : go(&gcn_halo_fwd_kernel<gcl::kActNone, 4, 2, true, true, true>);
+  else if (hp4 <= 4 && form_env)
+    rc = act == GCL_ACT_PRELU  ? go(&gcn_halo_fwd_kernel<gcl::kActPrelu, 4, 2, true, true>)
+         : act == GCL_ACT_SILU ? go(&gcn_halo_fwd_kernel<gcl::kActSilu, 4, 2, true, true>)
+                               : go(&gcn_halo_fwd_kernel<gcl::kActNone, 4, 2, true, true>);
+  else if (hp4 <= 4)
+    rc = act == GCL_ACT_PRELU  ? go(&gcn_halo_fwd_kernel<gcl::kActPrelu, 4>)
+         : act == GCL_ACT_SILU ? go(&gcn_halo_fwd_kernel<gcl::kActSilu, 4>)
+                               : go(&gcn_halo_fwd_kernel<gcl::kActNone, 4>);
+  else
+    rc = act == GCL_ACT_PRELU  ? go(&gcn_halo_fwd_kernel<gcl::kActPrelu, 8, 2, true>)
+         : act == GCL_ACT_SILU ? go(&gcn_halo_fwd_kernel<gcl::kActSilu, 8, 2, true>)
+                               : go(&gcn_halo_fwd_kernel<gcl::kActNone, 8, 2, true>);
+  if (rc) return rc;
+  GCL_CHECK_LAUNCH();
+  *launched = true;
+  return GCL_OK;
+}
+
 extern "C" int gcl_gcn_layer_fwd(const gcl_graph_t* g, const float* x, int64_t ldx, int64_t bsx, int32_t act,
                                  const float* slope, const float* W, const float* bias, float* y, int64_t ldy,
                                  int64_t bsy, int32_t B, int32_t Fin, int32_t Fout, int32_t Fout_store,
@@ -966,52 +1049,10 @@ extern "C" int gcl_gcn_layer_fwd_rows(const gcl_graph_t* g, const float* x, int6
   GCL_CHECK_ARG(rows_out >= 1 && rows_out <= n, "gcn_layer_fwd: rows_out=%d outside [1, n=%d]", rows_out, n);
   hipStream_t st = (hipStream_t)stream;
   {
-    // source-tile form: graphs with a tile layout (mesh rows in tile order), 64-wide rows, split-operand dense part
-    const int halo_on = env_int("GCL_GCN_HALO", 1);  // read per call: the parity test compares the two kernels
-    static const int x3_on = env_int("GCL_X3", 1) && env_int("GCL_X3_GCN", 1);
-    const gcl_halo& hl = g->halo[0][0];
-    const int hp4 = hl.T == 64 ? (int)gcl::cdiv((hl.smax - 64) / 4, 4) : 99;
-    const int KPh = Fin + 2;
-    const size_t ldsh = (size_t)2 * (32 * KPh > 2048 ? 32 * KPh : 2048) * 4 + (size_t)(hl.smax + 1) * 256;
-    // only where the gather is the bulk of the layer (>= 6 edges per row: the mesh graph has 7.4): on the decoder graph
-    // of the 512x256 configs (3.3 edges per row) the per-edge kernel's twelve wave-independent pipelines run 1.6x faster
-    if (halo_on && x3_on && g->kind == GCL_GRAPH_GCN && hl.T == 64 && hp4 <= 8 && Fin % 16 == 0 && Fin > 32 && rows_out == n &&
-        g->e >= 6 * (int64_t)n &&
-        ldsh <= 80 * 1024 && (int64_t)n * ldx * 4 < ((int64_t)1 << 31) && n < (1 << 24) && ldx * 4 < (1 << 24) &&
-        (int64_t)n * ldy * 4 < ((int64_t)1 << 31)) {
-      static const int bpc_env = env_int("GCL_GCN_HALO_BPC", 0);
-      const int per_cu = (int)((160 * 1024) / ldsh);
-      const int Jx = 32 * (bpc_env > 0 ? bpc_env : per_cu);
-      dim3 grid((unsigned)(gcl::kNumXCD * Jx));
-      auto go = [&](auto kern) -> int {
-        const int rc = gcl::ensure_dyn_lds((const void*)kern, ldsh);
-        if (rc) return rc;
-        hipLaunchKernelGGL(kern, grid, dim3(256), ldsh, st, hl.list, hl.cnt, reinterpret_cast<const int2*>(hl.rec), g->rowptr,
-                           hl.opos, g->w, hl.smax, x, ldx, bsx, slope, W, bias, y, ldy, bsy, n, B, Fin, Fout, Fout_store,
-                           hl.ntiles);
-        return GCL_OK;
-      };
-      int rc;
-      // hp4 <= 4 (the icosphere meshes: <= 64 halo rows per tile): non-temporal stores straight from the accumulator and
-      // the next item's DMA pieces issued between the k-steps of the dense part (in the step 111.5 -> 102.6 us per mesh
-      // layer; GCL_GCN_HALO_FORM=0 selects the first form - DMA issue up front, staged 16-byte stores - for comparison)
-      static const int form_env = env_int("GCL_GCN_HALO_FORM", 1);
-      if (hp4 <= 4 && form_env)
-        rc = act == GCL_ACT_PRELU  ? go(&gcn_halo_fwd_kernel<gcl::kActPrelu, 4, 2, true, true>)
-             : act == GCL_ACT_SILU ? go(&gcn_halo_fwd_kernel<gcl::kActSilu, 4, 2, true, true>)
-                                   : go(&gcn_halo_fwd_kernel<gcl::kActNone, 4, 2, true, true>);
-      else if (hp4 <= 4)
-        rc = act == GCL_ACT_PRELU  ? go(&gcn_halo_fwd_kernel<gcl::kActPrelu, 4>)
-             : act == GCL_ACT_SILU ? go(&gcn_halo_fwd_kernel<gcl::kActSilu, 4>)
-                                   : go(&gcn_halo_fwd_kernel<gcl::kActNone, 4>);
-      else
-        rc = act == GCL_ACT_PRELU  ? go(&gcn_halo_fwd_kernel<gcl::kActPrelu, 8, 2, true>)
-             : act == GCL_ACT_SILU ? go(&gcn_halo_fwd_kernel<gcl::kActSilu, 8, 2, true>)
-                                   : go(&gcn_halo_fwd_kernel<gcl::kActNone, 8, 2, true>);
-      if (rc) return rc;
-      GCL_CHECK_LAUNCH();
-      return GCL_OK;
-    }
+    bool launched = false;
+    const int rc = halo_layer_launch(g, x, ldx, bsx, nullptr, 0, act, slope, W, bias, y, ldy, bsy, B, Fin, Fout, Fout_store,
+                                     rows_out, st, &launched);
+    if (rc || launched) return rc;
   }
   const int32_t nRT = (int32_t)gcl::cdiv(rows_out, 32);  // only the tiles that hold requested rows are computed
   const int NS = Fout_store > 32 ? 2 : 1;
@@ -1083,4 +1124,49 @@ extern "C" int gcl_gcn_layer_fwd_rows(const gcl_graph_t* g, const float* x, int6
 #undef GCL_GF5
   GCL_CHECK_LAUNCH();
   return GCL_OK;
+}
+
+// The layer with its input rows read through a row table (gcn_halo_fwd_kernel<.., TAB>): row i of sample b is row
+// tab[i] of sample b of x when tab[i] >= 0, the batch-invariant flat row ~tab[i] of x otherwise.  Only the source-tile
+// form supports it: GCL_EUNSUPPORTED elsewhere (gcl_gcn_layer_fwd_tab_ok tells beforehand), and the caller
+// materialises the rows (gcl_gather2_rows) and calls gcl_gcn_layer_fwd instead.
+extern "C" int gcl_gcn_layer_fwd_tab(const gcl_graph_t* g, const float* x, int64_t ldx, int64_t bsx, int64_t x_rows,
+                                     const int32_t* tab, int32_t act, const float* slope, const float* W,
+                                     const float* bias, float* y, int64_t ldy, int64_t bsy, int32_t B, int32_t Fin,
+                                     int32_t Fout, int32_t Fout_store, gcl_stream_t stream) {
+  GCL_CHECK_ARG(g && x && W && y && tab, "gcn_layer_fwd_tab: null argument");
+  GCL_CHECK_ARG(g->kind == GCL_GRAPH_GCN, "gcn_layer_fwd_tab: graph carries no GCN edge weights");
+  GCL_CHECK_ARG(B > 0 && Fin >= 4 && Fin <= 64 && Fin % 4 == 0 && Fout >= 1 && Fout <= 64,
+                "gcn_layer_fwd_tab: unsupported Fin=%d Fout=%d (Fin %% 4 == 0, both <= 64)", Fin, Fout);
+  GCL_CHECK_ARG(Fout_store >= Fout && Fout_store % 4 == 0 && Fout_store <= 64 && ldy >= Fout_store,
+                "gcn_layer_fwd_tab: Fout_store=%d must be a multiple of 4 in [Fout, min(64, ldy)]", Fout_store);
+  GCL_CHECK_ARG(ldx >= Fin && ldx % 4 == 0 && bsx % 4 == 0 && gcl::aligned16(x) && x_rows >= 1,
+                "gcn_layer_fwd_tab: x rows must be 16-B aligned");
+  GCL_CHECK_ARG(ldy % 4 == 0 && bsy % 4 == 0 && gcl::aligned16(y), "gcn_layer_fwd_tab: y rows must be 16-B aligned");
+  GCL_CHECK_ARG(act == GCL_ACT_NONE || act == GCL_ACT_SILU || (act == GCL_ACT_PRELU && slope),
+                "gcn_layer_fwd_tab: bad activation %d", act);
+  bool launched = false;
+  const int rc = halo_layer_launch(g, x, ldx, bsx, tab, x_rows, act, slope, W, bias, y, ldy, bsy, B, Fin, Fout, Fout_store,
+                                   g->n, (hipStream_t)stream, &launched);
+  if (rc) return rc;
+  if (!launched) {
+    gcl::set_error("gcn_layer_fwd_tab: this graph / shape has no source-tile form (Fin=%d Fout=%d)", Fin, Fout);
+    return GCL_EUNSUPPORTED;
+  }
+  return GCL_OK;
+}
+
+extern "C" int gcl_gcn_layer_fwd_tab_ok(const gcl_graph_t* g, int64_t ldx, int64_t bsx, int64_t x_rows, int32_t B,
+                                        int32_t Fin, int32_t Fout) {
+  if (!g || g->kind != GCL_GRAPH_GCN || g->n_heavy) return 0;
+  static const int x3_on = env_int("GCL_X3", 1) && env_int("GCL_X3_GCN", 1);
+  const gcl_halo& hl = g->halo[0][0];
+  if (!env_int("GCL_GCN_HALO", 1) || !x3_on || hl.T != 64) return 0;
+  const int hp4 = (int)gcl::cdiv((hl.smax - 64) / 4, 4);
+  const size_t ldsh = (size_t)2 * (32 * (Fin + 2) > 2048 ? 32 * (Fin + 2) : 2048) * 4 + (size_t)(hl.smax + 1) * 256;
+  return hp4 <= 4 && Fin % 16 == 0 && Fin > 32 && Fin <= 64 && Fout >= 1 && Fout <= 64 && g->e >= 6 * (int64_t)g->n &&
+                 ldsh <= 80 * 1024 && x_rows * ldx * 4 < ((int64_t)1 << 32) && (int64_t)B * bsx * 4 < ((int64_t)1 << 32) &&
+                 x_rows < (1 << 24) && g->n < (1 << 24) && ldx * 4 < (1 << 24)
+             ? 1
+             : 0;
 }

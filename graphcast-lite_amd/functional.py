@@ -126,6 +126,57 @@ _LN_COLSUM = os.environ.get("GCL_NO_LN_COLSUM", "0") in ("0", "")
 _ROWS_OUT = os.environ.get("GCL_NO_ROWS_OUT", "0") in ("0", "")
 
 
+def _lat_first_layer_bwd(lat, enc3, dz3, W, dW, acc_dw: bool, want_dx: bool):
+    """Dense backward of a GCN stack's first layer whose input was read through a LatSource: dz3 [B, M, D'] is the
+    gradient of the layer's pre-aggregation rows (A^T dp).  Returns the gradient of the encoder output [B, ne, D] (or
+    None when the shared landing buffer took it / no gradient is wanted); dW is written / accumulated in place."""
+    _, _, inv_a, inv_fold = lat.maps
+    B, ne, D = enc3.shape
+    G, Md, r = lat.G, lat.Md, lat.r
+    nc = Md + r
+    Fo = dz3.shape[-1]
+    dz3 = dz3 if dz3.is_contiguous() else dz3.contiguous()
+    # compact gradient rows [B, Md + r, Fo]: dependent rows gathered, folded rows summed over the batch
+    dzc = torch.empty(B, nc, Fo, dtype=torch.float32, device=dz3.device)
+    if Md > 0:
+        hip.gather2_rows(dz3, inv_a[G: G + Md], None, None, Md, B, out=dzc[:, :Md])
+    if r > 0:
+        tmp = hip.gather2_rows(dz3, inv_fold, None, None, B * r, B, sum_batch=True)
+        hip.copy_rows(tmp.view(B, r, Fo), dzc[:, Md:])
+    Pc = hip.copy_rows(enc3[:, G:, :], torch.empty(B, nc, D, dtype=torch.float32, device=dz3.device))  # the encoder rows behind the mesh latents
+    land = lat.landing
+    shared = land is not None and land.buf is not None
+    if not want_dx:
+        hip.linear_bwd_dw(dzc.view(B * nc, Fo), Pc.view(B * nc, D), None, dW, None, acc_dw)
+        dxc = None
+    else:
+        dxc = hip.linear_bwd_all(dzc.view(B * nc, Fo), W, Pc.view(B * nc, D), None, None, dW, None, None, acc_dw,
+                                 act=hip.ACT_NONE).view(B, nc, D)
+    if shared:
+        if dxc is not None:
+            hip.copy_rows(dxc, land.buf[:, G:])  # head rows: written by the decoder-input gather's backward
+        land.buf, land.mesh_pending, land.handed_over = None, False, False
+        return None
+    if dxc is None:
+        return None
+    out = torch.zeros(B, ne, D, dtype=torch.float32, device=dz3.device)
+    hip.copy_rows(dxc, out[:, G:])
+    return out
+
+
+class LatSource:
+    """The mesh latents of the compact pipeline as a VIEW of the encoder output enc [B, ne, D] (rows per sample:
+    [G grid | Md batch-dependent mesh | r folded batch-invariant mesh rows], see MeshLatFn): mesh row i of sample b is
+    enc[b, tab[i]] (tab[i] >= 0) or the flat row ~tab[i] of enc viewed as [B * ne, D] (tab[i] < 0).  A GCN stack given
+    one reads its first layer's input through the table (gcl_gcn_layer_fwd_tab) - the [B, M, D] latents are never
+    written - and runs that layer's dense backward on the COMPACT rows: by linearity the gradient of a folded row is
+    (sum_b dz[b, i]) W and its dW term (sum_b dz[b, i])^T enc_row, so 81 % of the rows (64x32 grid) cost one batch sum
+    instead of B dense rows.  maps = MeshLatFn's (map_a, map_b, inv_a, inv_fold)."""
+
+    def __init__(self, tab, maps, M: int, G: int, Md: int, r: int, landing=None):
+        self.tab, self.maps, self.M, self.G, self.Md, self.r, self.landing = tab, maps, M, G, Md, r, landing
+
+
 class GCNStackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, owner, graph, L: int, has_ln: bool, eps: float, out_rows: int, *params):
@@ -135,6 +186,15 @@ class GCNStackFn(torch.autograd.Function):
         squeeze = x.dim() == 2
         x3 = _flat3(x.detach())
         B, n, _ = x3.shape
+        lat = getattr(owner, "_lat_src", None)
+        if lat is not None:
+            owner._lat_src = None
+            n = lat.M  # x is the encoder output [B, ne, D]; the stack runs on the M mesh rows it is read into
+            if not x3.is_contiguous():
+                x3 = x3.contiguous()
+            if lat.landing is not None:
+                lat.landing.mesh_pending = True  # this Function's backward fills the tail rows of the shared buffer (as MeshLatFn)
+        ctx.lat = lat
         slope_p = params[2 * L]
         # activation between the convs: learnable PReLU slope (params[2L]), SiLU, or ReLU as a PReLU
         # with the owner's constant zero slope (src/models.py:154-163, :316)
@@ -148,6 +208,13 @@ class GCNStackFn(torch.autograd.Function):
             Fout = W.shape[0]
             ldh = (Fout + 3) // 4 * 4  # padded scratch so the gather can use 16-B loads
             act_k, slope_k = (akind, slope_t) if k > 0 else (hip.ACT_NONE, None)
+            if k == 0 and lat is not None:
+                p = hip.gcn_layer_fwd_tab(graph, x3, lat.tab, act_k, slope_k, W, b)
+                if ldh != Fout:
+                    p = p.contiguous()
+                ps.append(p)
+                cur = p
+                continue
             if hip.gcn_layer_fusable(graph, cur, W.shape[1], Fout):
                 # ONE kernel (csrc/gcn_layer.hip): gather-aggregate the activated input rows, then the dense
                 # transform; an output width that is not a multiple of 4 (33 / 19 variables) is stored ldh wide
@@ -258,7 +325,7 @@ class GCNStackFn(torch.autograd.Function):
         for k in range(L - 1, -1, -1):
             W = params[2 * k].detach()
             wi = 2 * k
-            inp = (ctx.x3 if k == 0 else ps[k - 1]).view(B * n, -1)
+            inp = (ctx.x3 if k == 0 else ps[k - 1]).view(-1, (ctx.x3 if k == 0 else ps[k - 1]).shape[-1])
             dh2 = hip.aggregate(graph, dp, None, transpose=True).view(B * n, -1)
             if k == L - 1 and Fp != Fo:
                 dh2 = dh2[:, :Fo]  # [rows, Fout] view with row stride Fp
@@ -268,6 +335,8 @@ class GCNStackFn(torch.autograd.Function):
                 # conv k-1 (= column sums of dp_{k-1}), which accumulates by ITS parameter's state
                 dp = hip.linear_bwd_all(dh2, W, inp, slope_t, dsl, dW, None, G.dst[2 * k - 1], G.acc[wi],
                                         acc_colsum=G.acc[2 * k - 1], act=akind).view(B, n, -1)
+            elif ctx.lat is not None:
+                dx = _lat_first_layer_bwd(ctx.lat, ctx.x3, dh2.reshape(B, n, -1), W, dW, G.acc[wi], ctx.needs_input_grad[0])
             elif ctx.needs_input_grad[0]:
                 dx = hip.linear_bwd_all(dh2, W, inp, None, None, dW, None, None, G.acc[wi],
                                         act=hip.ACT_NONE).view(B, n, -1)

@@ -80,6 +80,8 @@ _SIGNATURES = {
                                    C.c_size_t, _vp]),
     "gcl_gcn_layer_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "gcl_gcn_layer_fwd_rows": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "gcl_gcn_layer_fwd_tab": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "gcl_gcn_layer_fwd_tab_ok": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _i32, _i32]),
     "gcl_segment_reduce": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "gcl_edge_combine": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i32, _i64, _i32, _vp]),
     "gcl_act_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
@@ -779,5 +781,28 @@ def gcn_layer_fwd(graph: Graph, x3, act, slope, W, bias, out=None, rows_out=None
     _check(lib().gcl_gcn_layer_fwd_rows(graph.handle, _p(x3), x3.stride(1), x3.stride(0), int(act), _p(slope),
                                         _p(W.contiguous()), _p(bias), _p(out), out.stride(1), out.stride(0), B, Fin, Fout,
                                         Fst, int(rows_out) if rows_out else n, _stream()))
+    _probe_end(tok)
+    return out[..., :Fout]
+
+
+def gcn_layer_tab_ok(graph: Graph, x3, Fout: int) -> bool:
+    """True when gcn_layer_fwd_tab would run on x3 [B, rows, Fin] (source-tile graph, 48 / 64-wide rows, 32-bit offsets)."""
+    B, nx, Fin = x3.shape
+    return bool(lib().gcl_gcn_layer_fwd_tab_ok(graph.handle, x3.stride(1), x3.stride(0), B * nx, B, Fin, int(Fout)))
+
+
+def gcn_layer_fwd_tab(graph: Graph, x3, tab, act, slope, W, bias):
+    """The one-kernel GCNConv layer whose input row i of sample b is x3[b, tab[i]] (tab[i] >= 0) or the batch-invariant
+    row ~tab[i] of x3 viewed as [B * rows, Fin] (tab[i] < 0): the mesh latents of the compact pipeline are never
+    materialised (see gcl_gcn_layer_fwd_tab).  x3 [B, rows, Fin] contiguous, tab int32 [graph.n]."""
+    B, nx, Fin = x3.shape
+    assert x3.is_contiguous() and tab.dtype == torch.int32 and tab.numel() == graph.n
+    Fout = W.shape[0]
+    Fst = (Fout + 3) // 4 * 4
+    out = torch.empty(B, graph.n, Fst, dtype=torch.float32, device=x3.device)
+    tok = _probe_begin("gcn_layer_fwd", graph=graph, B=B, Fin=Fin, Fout=Fout)
+    _check(lib().gcl_gcn_layer_fwd_tab(graph.handle, _p(x3), x3.stride(1), x3.stride(0), B * nx, _pi(tab), int(act), _p(slope),
+                                       _p(W.contiguous()), _p(bias), _p(out), out.stride(1), out.stride(0), B, Fin, Fout, Fst,
+                                       _stream()))
     _probe_end(tok)
     return out[..., :Fout]

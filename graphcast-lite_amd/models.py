@@ -42,7 +42,7 @@ from .config import (
 from .create_graphs import (create_decoding_graph, create_encoding_graph, create_processing_graph,
                             create_product_graph)
 from .functional import (AssembleFn, EdgeLayout, GATLayerFn, Gather2Fn, GCNStackFn, GradLanding, GraphNormFn, InteractionNetFn,
-                         LayerNormFn, MeanAggFn, MeshLatFn, MLPFn)
+                         LatSource, LayerNormFn, MeanAggFn, MeshLatFn, MLPFn)
 from .mesh import get_hierarchy_of_triangular_meshes_for_sphere, get_mesh_lat_long, prune_mesh_to_region, tile_order
 
 
@@ -402,7 +402,8 @@ class GraphLayer(nn.Module):
             if edge_attr is None:
                 raise ValueError("InteractionNet requires edge_attr (edge features)")
             return self.layers(x=X, edge_index=edge_index, edge_attr_raw=edge_attr)
-        n = _num_nodes(X)
+        lat_src = kwargs.get("_lat_src") if self.layer_type == GraphLayerType.ConvGCN else None
+        n = lat_src.M if lat_src is not None else _num_nodes(X)  # with a LatSource X is the encoder output, the graph the mesh
         ln = self._final_ln()
         fuse_ln = ln is not None and ln.mode == "node"
 
@@ -417,6 +418,7 @@ class GraphLayer(nn.Module):
             g = _graphs.get(edge_index, n, hip.GRAPH_GCN)
             out_rows = int(kwargs.get("_out_rows") or 0)  # the caller keeps only the first rows (decoder: grid rows)
             self._grad_src = kwargs.get("_grad_src") if fuse_ln else None  # functional.GradLanding (picked up by GCNStackFn)
+            self._lat_src = lat_src  # functional.LatSource (picked up by GCNStackFn): X is read through a row table
             if ln is not None and not fuse_ln:
                 X = GCNStackFn.apply(X, self, g, len(convs), False, 1e-5, 0, *params)
                 X = ln(X)
@@ -722,6 +724,9 @@ class WeatherPrediction(nn.Module):
             map_b = map_b[c.perm[0]]
             inv_fold[:Mi] = c.perm[1][c.mi]
         f.maps = (c.maps_mesh[0], i32(map_b), c.maps_mesh[2], i32(inv_fold))
+        # the same two maps as ONE row table for consumers that read the mesh latents through it (gcl_gcn_layer_fwd_tab):
+        # entry >= 0: row of the sample's own encoder output, entry < 0: ~(flat row of the batch-invariant list)
+        f.tab = torch.where(f.maps[0] >= 0, f.maps[0], -f.maps[1] - 1).to(torch.int32).contiguous()
         # decoder-input maps: the encoder output now has ne rows per sample, the folded ones feed nothing there
         dinv_a = torch.cat([c.maps_dec[2], torch.full((r,), -1, dtype=torch.int32, device=device)]).contiguous()
         f.maps_dec = (c.maps_dec[0], c.maps_dec[1], dinv_a, c.maps_dec[3])
@@ -744,11 +749,14 @@ class WeatherPrediction(nn.Module):
             x_c = AssembleFn.apply(X3, self.init_grid_features, f.mstat, f.x_fold if f.r > 0 else None)  # [B, G+Md+r, C]
             enc_c = self.encoder.forward(X=x_c, edge_index=c.enc_graph)             # [B, G+Md+r, D]
             land = GradLanding(G) if kwargs.pop("_landing", False) and self._grad_landing else None
-            mesh_lat = MeshLatFn.apply(enc_c, f.maps, M, G + c.Md, f.r, land)       # [B, M, D]
+            lat_src = self._lat_source(c, f, enc_c, land)
+            if lat_src is None:
+                mesh_lat = MeshLatFn.apply(enc_c, f.maps, M, G + c.Md, f.r, land)   # [B, M, D]
             maps_dec = f.maps_dec
         else:
             kwargs.pop("_landing", None)
             land = None
+            lat_src = None
             maps_dec = c.maps_dec
             x_c = AssembleFn.apply(X3, self.init_grid_features, c.mstat_dep)           # [B, G+Md, C]
             enc_c = self.encoder.forward(X=x_c, edge_index=c.enc_graph)                 # [B, G+Md, D]
@@ -765,8 +773,14 @@ class WeatherPrediction(nn.Module):
                                                edge_attr=self._processing_edge_features)
         else:
             pg = self._processing_graph_tiled() if c.perm is not None else self.processing_graph
-            processed = self.processor.forward(X=mesh_lat, edge_index=pg, attention_threshold=attention_threshold,
-                                               **({"_grad_src": land} if land is not None else {}))
+            if lat_src is not None:
+                # the first GCNConv reads the mesh latents THROUGH the row table from the encoder output: they are never
+                # materialised, and its backward works on the compact rows (functional.GCNStackFn, LatSource)
+                processed = self.processor.forward(X=enc_c, edge_index=pg, attention_threshold=attention_threshold,
+                                                   _lat_src=lat_src, **({"_grad_src": land} if land is not None else {}))
+            else:
+                processed = self.processor.forward(X=mesh_lat, edge_index=pg, attention_threshold=attention_threshold,
+                                                   **({"_grad_src": land} if land is not None else {}))
         dec_in = Gather2Fn.apply(enc_c, processed, maps_dec, G + c.U, B, land)      # [B, G+U, D]
         gcn_dec = self.decoder.graph_layer.layer_type == GraphLayerType.ConvGCN
         decoded = self.decoder.forward(X=dec_in, edge_index=c.dec_graph, **({"_out_rows": G} if gcn_dec else {}))
@@ -776,6 +790,24 @@ class WeatherPrediction(nn.Module):
         if squeeze:
             return out[0], grid_lat[0], processed[0]
         return out, grid_lat, processed
+
+    _lat_through_table = os.environ.get("GCL_NO_LAT_TABLE", "0") in ("0", "")
+
+    def _lat_source(self, c, f, enc_c, land):
+        """functional.LatSource when the processor's first layer can read the mesh latents through the row table
+        (a GCNConv stack on a source-tile mesh graph, gcl_gcn_layer_fwd_tab), else None."""
+        if not self._lat_through_table or c.perm is None or self.processor.mlp is not None:
+            return None
+        gl = self.processor.graph_layer
+        if gl.layer_type != GraphLayerType.ConvGCN:
+            return None
+        convs = [m for m in gl.layers if isinstance(m, GCNConv)]
+        if not convs or enc_c.dim() != 3 or convs[0].lin.weight.shape[1] != enc_c.shape[-1]:
+            return None
+        g = _graphs.get(self._processing_graph_tiled(), self._num_mesh_nodes, hip.GRAPH_GCN)
+        if not hip.gcn_layer_tab_ok(g, enc_c, convs[0].lin.weight.shape[0]):
+            return None
+        return LatSource(f.tab, f.maps, self._num_mesh_nodes, self._num_grid_nodes, c.Md, f.r, land)
 
     _want_prediction_only = False
 

@@ -330,6 +330,17 @@ int gcl_gcn_layer_fwd_rows(const gcl_graph_t* g, const float* x, int64_t ldx, in
                            const float* slope, const float* W /*[Fout,Fin]*/, const float* bias, float* y,
                            int64_t ldy, int64_t bsy, int32_t B, int32_t Fin, int32_t Fout, int32_t Fout_store,
                            int32_t rows_out, gcl_stream_t stream);
+/* Same layer with its input rows read THROUGH a row table instead of from a materialised [B, n, Fin] tensor (the
+ * stage split of src/models.py:837-838 - `mesh_node_features = encoded[..., G:, :]` - folded into the first processor
+ * layer's loads): input row i of sample b is row tab[i] of sample b of x when tab[i] >= 0, and row ~tab[i] of x viewed
+ * as ONE flat list of x_rows rows (a batch-invariant row, shared by all samples) when tab[i] < 0.  Source-tile graphs
+ * only (gcn_halo_fwd_kernel): GCL_EUNSUPPORTED otherwise; gcl_gcn_layer_fwd_tab_ok returns 1 when the call would run. */
+int gcl_gcn_layer_fwd_tab(const gcl_graph_t* g, const float* x, int64_t ldx, int64_t bsx, int64_t x_rows,
+                          const int32_t* tab /*[n]*/, int32_t act, const float* slope, const float* W /*[Fout,Fin]*/,
+                          const float* bias, float* y, int64_t ldy, int64_t bsy, int32_t B, int32_t Fin, int32_t Fout,
+                          int32_t Fout_store, gcl_stream_t stream);
+int gcl_gcn_layer_fwd_tab_ok(const gcl_graph_t* g, int64_t ldx, int64_t bsx, int64_t x_rows, int32_t B, int32_t Fin,
+                             int32_t Fout);
 
 /* ---------------------------------------------------------------------------------------------
  * Edge-wise glue of the InteractionNet processor (src/models.py:206-236); csrc/interaction.hip.

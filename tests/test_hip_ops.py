@@ -885,6 +885,31 @@ def test_gcn_layer_fwd_source_tiles(hip, levels, Fin, Fout, B, act, monkeypatch)
     assert rel(outs["1"][: min(B, 3), pos], ref) < TOL
 
 
+@pytest.mark.parametrize("levels,Fin,Fout,B,act", [([3, 5], 64, 64, 9, 0), ([3, 5], 64, 64, 64, 1), ([2, 4], 48, 33, 3, 2)])
+def test_gcn_layer_fwd_through_row_table(hip, levels, Fin, Fout, B, act):
+    """gcl_gcn_layer_fwd_tab: the layer's input row i of sample b is x[b, tab[i]] or the batch-invariant flat row
+    ~tab[i] of x (the compact pipeline's mesh latents read straight from the encoder output).  BIT-equal to the same
+    layer on the materialised rows."""
+    g = build_graphs(experiment("baseline", mesh_levels=levels))
+    n = g["M"]
+    ei_t, order, pos = _tiled(g)
+    gh = hip.Graph(ei_t, n, hip.GRAPH_GCN)
+    ne = n // 3 + 17
+    gen = torch.Generator().manual_seed(5)
+    x = rnd(B, ne, Fin, seed=1)
+    own = torch.rand(n, generator=gen) < 0.2
+    tab = torch.where(own, torch.randint(0, ne, (n,), generator=gen), -torch.randint(0, B * ne, (n,), generator=gen) - 1).to(torch.int32)
+    lat = torch.where(own[None, :, None], x[:, tab.clamp(min=0).long()], x.reshape(B * ne, Fin)[(-tab.long() - 1).clamp(min=0)][None])
+    a = torch.tensor([0.25])
+    W, b = rnd(Fout, Fin, seed=2, scale=0.2), rnd(Fout, seed=3)
+    xd = x.to(DEV)
+    assert hip.gcn_layer_tab_ok(gh, xd, Fout)
+    sl = a.to(DEV) if act == 1 else None
+    got = hip.gcn_layer_fwd_tab(gh, xd, tab.to(DEV), act, sl, W.to(DEV), b.to(DEV)).cpu()
+    ref = hip.gcn_layer_fwd(gh, lat.contiguous().to(DEV), act, sl, W.to(DEV), b.to(DEV)).cpu()
+    assert torch.equal(got, ref), f"{(got != ref).sum().item()} elements differ"
+
+
 @pytest.mark.parametrize("rows,Fin,Fout", [(1000, 256, 256), (777, 512, 256), (300, 256, 128), (129, 160, 384)])
 def test_x3_wide_contractions_exact_on_integers(hip, rows, Fin, Fout):
     """gemm_tile_x3_kernel (csrc/gemm_tile.h: the wide layers of configs[3]/[4] and the InteractionNet MLPs) on small
