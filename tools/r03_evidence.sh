@@ -27,6 +27,7 @@ pmc)
   cp profiles/pmc_roofline_*.json $O/ ;;
 micro)
   timeout -k 10 300 python3 tools/kbench.py > $O/kbench_baseline_b64.txt 2>&1
+  timeout -k 10 300 python3 tools/kbench.py --only agg,gcn --ring 4 > $O/kbench_baseline_b64_ring4.txt 2>&1
   timeout -k 10 200 python3 tools/kbench.py --only gat > $O/kbench_attention_gat.txt 2>&1
   timeout -k 10 200 python3 tools/halo_check.py > $O/halo_check_mesh35_f64_b64.txt 2>&1
   timeout -k 10 200 python3 tools/halo_check.py --levels 4,6 --F 128 --B 8 > $O/halo_check_mesh46_f128_b8.txt 2>&1
