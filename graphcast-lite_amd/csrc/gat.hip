@@ -493,7 +493,10 @@ __device__ __forceinline__ float row_ror(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, true));
 }
 
-template <int LPR, int MAXPW>
+// TAB: the rows of h are read through a row table (row i of sample b = row tab[i] of sample b of Hf when tab[i] >= 0,
+// the batch-invariant flat row ~tab[i] of Hf otherwise): the compact pipeline's first GAT layer transforms only the
+// compact rows (functional.LatSource) and the [B, M, C] tensor of transformed mesh rows is never written.
+template <int LPR, int MAXPW, bool TAB = false>
 __global__ __launch_bounds__(256) void gat_halo_fwd_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ cnt,
                                                            const int2* __restrict__ rec, const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ opos, int32_t smax,
@@ -502,7 +505,8 @@ __global__ __launch_bounds__(256) void gat_halo_fwd_kernel(const int32_t* __rest
                                                            const float* __restrict__ bias, float* __restrict__ a_src,
                                                            float* __restrict__ a_dst, float* __restrict__ alpha,
                                                            float* __restrict__ Y, int64_t ldy, int64_t bsy, int32_t n,
-                                                           int64_t Ep, int32_t B, int32_t C, int32_t ntiles) {
+                                                           int64_t Ep, int32_t B, int32_t C, int32_t ntiles,
+                                                           const int32_t* __restrict__ tab = nullptr) {
   using gcl::halo::row_bcast;
   extern __shared__ float4 img[];  // [(smax + 1) * LPR] staged rows + zero row | sS[smax + 1] | sD[64]
   constexpr int T = 64, NW = 4;
@@ -538,6 +542,7 @@ __global__ __launch_bounds__(256) void gat_halo_fwd_kernel(const int32_t* __rest
   asm volatile("" : "+v"(bz.x), "+v"(bz.y), "+v"(bz.z), "+v"(bz.w));
 
   int jj[MAXPW], nhalo = 0, tile = -1;
+  int own[TAB ? NIT : 1];
   int2 rc[NIT];
   int rstart[NIT];
   while (true) {
@@ -558,22 +563,34 @@ __global__ __launch_bounds__(256) void gat_halo_fwd_kernel(const int32_t* __rest
           const int jr = tl[e0 + r];
           jv = sub == r ? jr : jv;
         }
-        jj[q] = jv;
+        jj[q] = TAB ? tab[jv] : jv;
+      }
+      if (TAB) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int row = tile * T + wave * (T / NW) + sub + it * RPW;
+          own[TAB ? it : 0] = tab[row < n ? row : n - 1];
+        }
       }
     }
     const char* Hc = reinterpret_cast<const char*>(Hf + (int64_t)b * bsh);
+    const char* H0 = reinterpret_cast<const char*>(Hf);
+    const unsigned sboff = (unsigned)b * (unsigned)bsh * 4u;
     const int row0 = tile * T + wave * (T / NW) + sub;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int row = row0 + it * RPW;
-      const char* src = Hc + (__umul24(row < n ? row : n - 1, ldb) + cb);
+      const int sr = TAB ? own[TAB ? it : 0] : (row < n ? row : n - 1);
+      // TAB: one base and a 32-bit byte offset (the whole of Hf stays below 4 GiB: checked on the host)
+      const char* src = TAB ? H0 + ((sr >= 0 ? sboff + __umul24(sr, ldb) : __umul24(~sr, ldb)) + cb) : Hc + (__umul24(sr, ldb) + cb);
       __builtin_amdgcn_global_load_lds((gcl::halo::gptr_t)src, (gcl::halo::lptr_t)(img + (wave * (T / NW) + it * RPW) * LPR), 16, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < MAXPW; ++q) {
       const int p = wave + NW * q;
       if (p < nhalo) {
-        const char* src = Hc + (__umul24(jj[q], ldb) + cb);
+        const int sr = jj[q];
+        const char* src = TAB ? H0 + ((sr >= 0 ? sboff + __umul24(sr, ldb) : __umul24(~sr, ldb)) + cb) : Hc + (__umul24(sr, ldb) + cb);
         __builtin_amdgcn_global_load_lds((gcl::halo::gptr_t)src, (gcl::halo::lptr_t)(img + (T + p * RPW) * LPR), 16, 0, 0);
       }
     }
@@ -697,13 +714,14 @@ __global__ __launch_bounds__(256) void gat_halo_fwd_kernel(const int32_t* __rest
 //     carry in place of a weight.
 // Rows with more than 16 edges take the CSR loop; heavy rows (> 64) keep such graphs on the per-edge kernels.
 // ---------------------------------------------------------------------------------------------------------
-template <int LPR, int MAXPW>
+template <int LPR, int MAXPW, bool TAB = false>
 __global__ __launch_bounds__(256) void gat_halo_bwd_dst_kernel(
     const int32_t* __restrict__ list, const int32_t* __restrict__ cnt, const int2* __restrict__ rec,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ opos, int32_t smax, const float* __restrict__ dY,
     int64_t lddy, int64_t bsdy, const float* __restrict__ Hf, int64_t ldh, int64_t bsh, const float* __restrict__ a_s,
     const float* __restrict__ a_d, const float* __restrict__ alpha, float* __restrict__ de, float* __restrict__ dad,
-    float* __restrict__ part, int32_t n, int64_t Ep, int32_t B, int32_t C, int32_t ntiles) {
+    float* __restrict__ part, int32_t n, int64_t Ep, int32_t B, int32_t C, int32_t ntiles,
+    const int32_t* __restrict__ tab = nullptr) {
   using gcl::halo::row_bcast;
   extern __shared__ float4 img[];  // [(smax + 1) * LPR] staged h rows + zero row | sS[64 + 128 + 8]: a_s of the staged rows (4-byte DMAs of 64 lanes)
   constexpr int T = 64, NW = 4;
@@ -740,6 +758,7 @@ __global__ __launch_bounds__(256) void gat_halo_bwd_dst_kernel(
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
   int jj[MAXPW], nhalo = 0, tile = -1;
   int hl0 = 0, hl1 = 0;  // wave 0: the halo list, one entry per lane (and lane + 64)
+  int own[TAB ? NIT : 1];
   int2 rc[NIT];
   int rstart[NIT];
   while (true) {
@@ -760,26 +779,38 @@ __global__ __launch_bounds__(256) void gat_halo_bwd_dst_kernel(
           const int jr = tl[e0 + r];
           jv = sub == r ? jr : jv;
         }
-        jj[q] = jv;
+        jj[q] = TAB ? tab[jv] : jv;
       }
       if (wave == 0) {
         hl0 = tl[min(lane, hstride - 1)];
         hl1 = tl[min(lane + 64, hstride - 1)];
       }
+      if (TAB) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int row = tile * T + wave * (T / NW) + sub + it * RPW;
+          own[TAB ? it : 0] = tab[row < n ? row : n - 1];
+        }
+      }
     }
     const char* Hc = reinterpret_cast<const char*>(Hf + (int64_t)b * bsh);
+    const char* H0 = reinterpret_cast<const char*>(Hf);
+    const unsigned sboff = (unsigned)b * (unsigned)bsh * 4u;
     const int row0 = tile * T + wave * (T / NW) + sub;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int row = row0 + it * RPW;
-      const char* src = Hc + (__umul24(row < n ? row : n - 1, ldb) + cb);
+      const int sr = TAB ? own[TAB ? it : 0] : (row < n ? row : n - 1);
+      // TAB: one base and a 32-bit byte offset (the whole of Hf stays below 4 GiB: checked on the host)
+      const char* src = TAB ? H0 + ((sr >= 0 ? sboff + __umul24(sr, ldb) : __umul24(~sr, ldb)) + cb) : Hc + (__umul24(sr, ldb) + cb);
       __builtin_amdgcn_global_load_lds((gcl::halo::gptr_t)src, (gcl::halo::lptr_t)(img + (wave * (T / NW) + it * RPW) * LPR), 16, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < MAXPW; ++q) {
       const int p = wave + NW * q;
       if (p < nhalo) {
-        const char* src = Hc + (__umul24(jj[q], ldb) + cb);
+        const int sr = jj[q];
+        const char* src = TAB ? H0 + ((sr >= 0 ? sboff + __umul24(sr, ldb) : __umul24(~sr, ldb)) + cb) : Hc + (__umul24(sr, ldb) + cb);
         __builtin_amdgcn_global_load_lds((gcl::halo::gptr_t)src, (gcl::halo::lptr_t)(img + (T + p * RPW) * LPR), 16, 0, 0);
       }
     }
@@ -1158,9 +1189,10 @@ inline int chunk_heads(int H, int h0, int maxc) {
     default: CALL(64); break;       \
   }
 
-extern "C" int gcl_gat_fwd(const gcl_graph_t* g, const float* h, int64_t ldh, int64_t bsh, const float* att_src,
-                           const float* att_dst, const float* bias, float* a_src, float* a_dst, float* alpha,
-                           float* y, int64_t ldy, int64_t bsy, int32_t B, int32_t H, int32_t C, gcl_stream_t stream) {
+static int gat_fwd_impl(const gcl_graph_t* g, const float* h, int64_t ldh, int64_t bsh, const int32_t* tab,
+                        const float* att_src, const float* att_dst, const float* bias, float* a_src, float* a_dst,
+                        float* alpha, float* y, int64_t ldy, int64_t bsy, int32_t B, int32_t H, int32_t C,
+                        gcl_stream_t stream) {
   int maxc = 0;
   int rc = gat_check(g, H, C, &maxc);
   if (rc) return rc;
@@ -1189,17 +1221,24 @@ extern "C" int gcl_gat_fwd(const gcl_graph_t* g, const float* h, int64_t ldh, in
           if (rc2) return rc2;
           hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)ldsb, st, hl.list, hl.cnt, reinterpret_cast<const int2*>(hl.rec),
                              g->rowptr, hl.opos, hl.smax, h, ldh, bsh, att_src, att_dst, bias, a_src, a_dst, alpha, y, ldy,
-                             bsy, g->n, g->e, B, C, hl.ntiles);
+                             bsy, g->n, g->e, B, C, hl.ntiles, tab);
           return GCL_OK;
         };
         int rc2;
-        if (lprh == 16) rc2 = mpw <= 4 ? go(&gat_halo_fwd_kernel<16, 4>) : mpw <= 8 ? go(&gat_halo_fwd_kernel<16, 8>) : go(&gat_halo_fwd_kernel<16, 16>);
+        if (tab) {
+          if (lprh == 16) rc2 = mpw <= 4 ? go(&gat_halo_fwd_kernel<16, 4, true>) : mpw <= 8 ? go(&gat_halo_fwd_kernel<16, 8, true>) : go(&gat_halo_fwd_kernel<16, 16, true>);
+          else rc2 = mpw <= 4 ? go(&gat_halo_fwd_kernel<32, 4, true>) : mpw <= 8 ? go(&gat_halo_fwd_kernel<32, 8, true>) : go(&gat_halo_fwd_kernel<32, 16, true>);
+        } else if (lprh == 16) rc2 = mpw <= 4 ? go(&gat_halo_fwd_kernel<16, 4>) : mpw <= 8 ? go(&gat_halo_fwd_kernel<16, 8>) : go(&gat_halo_fwd_kernel<16, 16>);
         else rc2 = mpw <= 4 ? go(&gat_halo_fwd_kernel<32, 4>) : mpw <= 8 ? go(&gat_halo_fwd_kernel<32, 8>) : go(&gat_halo_fwd_kernel<32, 16>);
         if (rc2) return rc2;
         GCL_CHECK_LAUNCH();
         return GCL_OK;
       }
     }
+  }
+  if (tab) {
+    gcl::set_error("gat_fwd_tab: this graph / shape has no source-tile form (H=%d C=%d)", H, C);
+    return GCL_EUNSUPPORTED;
   }
   for (int h0 = 0; h0 < H;) {
     const int hc = chunk_heads(H, h0, maxc);
@@ -1230,6 +1269,42 @@ extern "C" int gcl_gat_fwd(const gcl_graph_t* g, const float* h, int64_t ldh, in
   return GCL_OK;
 }
 
+extern "C" int gcl_gat_fwd(const gcl_graph_t* g, const float* h, int64_t ldh, int64_t bsh, const float* att_src,
+                           const float* att_dst, const float* bias, float* a_src, float* a_dst, float* alpha,
+                           float* y, int64_t ldy, int64_t bsy, int32_t B, int32_t H, int32_t C, gcl_stream_t stream) {
+  return gat_fwd_impl(g, h, ldh, bsh, nullptr, att_src, att_dst, bias, a_src, a_dst, alpha, y, ldy, bsy, B, H, C, stream);
+}
+
+// The rows of h read through a row table (gat_halo_*_kernel<.., TAB>): row i of sample b is row tab[i] of sample b of h
+// when tab[i] >= 0, the batch-invariant flat row ~tab[i] of h otherwise.  One head on a source-tile graph only
+// (gcl_gat_tab_ok tells beforehand); GCL_EUNSUPPORTED elsewhere.
+extern "C" int gcl_gat_fwd_tab(const gcl_graph_t* g, const float* h, int64_t ldh, int64_t bsh, const int32_t* tab,
+                               const float* att_src, const float* att_dst, const float* bias, float* a_src,
+                               float* a_dst, float* alpha, float* y, int64_t ldy, int64_t bsy, int32_t B, int32_t H,
+                               int32_t C, gcl_stream_t stream) {
+  GCL_CHECK_ARG(tab, "gat_fwd_tab: null row table");
+  GCL_CHECK_ARG((int64_t)B * bsh * 4 < ((int64_t)1 << 32), "gat_fwd_tab: h must stay below 4 GiB (32-bit row offsets)");
+  return gat_fwd_impl(g, h, ldh, bsh, tab, att_src, att_dst, bias, a_src, a_dst, alpha, y, ldy, bsy, B, H, C, stream);
+}
+
+extern "C" int gcl_gat_tab_ok(const gcl_graph_t* g, int64_t ldh, int32_t H, int32_t C) {
+  if (!g || g->kind != GCL_GRAPH_GAT || H != 1 || !(C == 64 || C == 128) || g->n_heavy || g->n_theavy) return 0;
+  const char* ev = getenv("GCL_GAT_HALO");
+  if (ev && atoi(ev) == 0) return 0;
+  const gcl_halo& hf = g->halo[0][0];
+  const gcl_halo& ht = g->halo[1][0];
+  if (hf.T != 64 || ht.T != 64) return 0;
+  const int lprh = C / 4, rpw = 64 / lprh;
+  const int64_t ldsf = (int64_t)(hf.smax + 1) * lprh * 16 + (int64_t)(hf.smax + 1 + 64) * 4;
+  const int64_t ldsd = (int64_t)(hf.smax + 1) * lprh * 16 + (int64_t)(64 + 128 + 8) * 4;
+  const int64_t ldss = (int64_t)(ht.smax + 1) * lprh * 16;
+  const int mpd = (int)gcl::cdiv((hf.smax - 64) / rpw, 4), mps = (int)gcl::cdiv((ht.smax - 64) / rpw, 4);
+  return ldsf <= 80 * 1024 && ldsd <= 80 * 1024 && ldss <= 80 * 1024 && hf.smax - 64 <= 128 && mpd <= 16 && mps <= 16 &&
+                 ldh * 4 < (1 << 24) && g->n < (1 << 24)
+             ? 1
+             : 0;
+}
+
 extern "C" size_t gcl_gat_bwd_ws_bytes(int64_t e_prime, int32_t n, int32_t B, int32_t H, int32_t C) {
   const size_t de = (size_t)B * e_prime * H;
   const size_t nodes = (size_t)B * n * H * 2;  // da_d, da_s
@@ -1240,11 +1315,11 @@ extern "C" size_t gcl_gat_bwd_ws_bytes(int64_t e_prime, int32_t n, int32_t B, in
 extern "C" int gcl_colsum(const float*, int64_t, int64_t, int32_t, float*, int32_t, void*, size_t, gcl_stream_t);
 extern "C" size_t gcl_colsum_ws_bytes(int64_t, int32_t);
 
-extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, int64_t bsdy, const float* h,
-                           int64_t ldh, int64_t bsh, const float* att_src, const float* att_dst, const float* a_src,
-                           const float* a_dst, const float* alpha, float* dh, int64_t lddh, int64_t bsdh,
-                           float* d_att_src, float* d_att_dst, float* d_bias, int32_t accumulate, int32_t B, int32_t H,
-                           int32_t C, void* ws, size_t ws_bytes, gcl_stream_t stream) {
+static int gat_bwd_impl(const gcl_graph_t* g, const float* dy, int64_t lddy, int64_t bsdy, const float* h, int64_t ldh,
+                        int64_t bsh, const int32_t* tab, const float* att_src, const float* att_dst, const float* a_src,
+                        const float* a_dst, const float* alpha, float* dh, int64_t lddh, int64_t bsdh, float* d_att_src,
+                        float* d_att_dst, float* d_bias, int32_t accumulate, int32_t B, int32_t H, int32_t C, void* ws,
+                        size_t ws_bytes, gcl_stream_t stream) {
   int maxc = 0;
   int rc = gat_check(g, H, C, &maxc);
   if (rc) return rc;
@@ -1289,7 +1364,7 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
           const int per_cu = (int)std::min<int64_t>(8, (160 * 1024) / ldsd);
           hipLaunchKernelGGL(kern, dim3((unsigned)(gcl::kNumXCD * 32 * per_cu)), dim3(256), (size_t)ldsd, st, hf.list, hf.cnt,
                              reinterpret_cast<const int2*>(hf.rec), g->rowptr, hf.opos, hf.smax, dy, lddy, bsdy, h, ldh, bsh,
-                             a_src, a_dst, alpha, de, dad, part, g->n, g->e, B, C, hf.ntiles);
+                             a_src, a_dst, alpha, de, dad, part, g->n, g->e, B, C, hf.ntiles, tab);
           halo_parts = (int)(gcl::kNumXCD * 32 * per_cu);
           return GCL_OK;
         };
@@ -1304,7 +1379,10 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
           return GCL_OK;
         };
         int rc2;
-        if (lprh == 16) rc2 = mpd <= 4 ? god(&gat_halo_bwd_dst_kernel<16, 4>) : mpd <= 8 ? god(&gat_halo_bwd_dst_kernel<16, 8>) : god(&gat_halo_bwd_dst_kernel<16, 16>);
+        if (tab) {
+          if (lprh == 16) rc2 = mpd <= 4 ? god(&gat_halo_bwd_dst_kernel<16, 4, true>) : mpd <= 8 ? god(&gat_halo_bwd_dst_kernel<16, 8, true>) : god(&gat_halo_bwd_dst_kernel<16, 16, true>);
+          else rc2 = mpd <= 4 ? god(&gat_halo_bwd_dst_kernel<32, 4, true>) : mpd <= 8 ? god(&gat_halo_bwd_dst_kernel<32, 8, true>) : god(&gat_halo_bwd_dst_kernel<32, 16, true>);
+        } else if (lprh == 16) rc2 = mpd <= 4 ? god(&gat_halo_bwd_dst_kernel<16, 4>) : mpd <= 8 ? god(&gat_halo_bwd_dst_kernel<16, 8>) : god(&gat_halo_bwd_dst_kernel<16, 16>);
         else rc2 = mpd <= 4 ? god(&gat_halo_bwd_dst_kernel<32, 4>) : mpd <= 8 ? god(&gat_halo_bwd_dst_kernel<32, 8>) : god(&gat_halo_bwd_dst_kernel<32, 16>);
         if (rc2) return rc2;
         GCL_CHECK_LAUNCH();
@@ -1315,6 +1393,10 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
         halo_done = true;
       }
     }
+  }
+  if (tab && !halo_done) {
+    gcl::set_error("gat_bwd_tab: this graph / shape has no source-tile form (H=%d C=%d)", H, C);
+    return GCL_EUNSUPPORTED;
   }
   for (int h0 = 0; h0 < H;) {
     const int hc = chunk_heads(H, h0, maxc);
@@ -1367,6 +1449,28 @@ extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, 
     if (rc) return rc;
   }
   return GCL_OK;
+}
+
+extern "C" int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, int64_t bsdy, const float* h,
+                           int64_t ldh, int64_t bsh, const float* att_src, const float* att_dst, const float* a_src,
+                           const float* a_dst, const float* alpha, float* dh, int64_t lddh, int64_t bsdh,
+                           float* d_att_src, float* d_att_dst, float* d_bias, int32_t accumulate, int32_t B, int32_t H,
+                           int32_t C, void* ws, size_t ws_bytes, gcl_stream_t stream) {
+  return gat_bwd_impl(g, dy, lddy, bsdy, h, ldh, bsh, nullptr, att_src, att_dst, a_src, a_dst, alpha, dh, lddh, bsdh,
+                      d_att_src, d_att_dst, d_bias, accumulate, B, H, C, ws, ws_bytes, stream);
+}
+
+// dh[b, i] is the gradient of the TABLE-READ row i of sample b (dense [B, n, C]); the caller folds it back onto the
+// rows behind the table (gather for tab >= 0, batch sum for the shared rows).
+extern "C" int gcl_gat_bwd_tab(const gcl_graph_t* g, const float* dy, int64_t lddy, int64_t bsdy, const float* h,
+                               int64_t ldh, int64_t bsh, const int32_t* tab, const float* att_src, const float* att_dst,
+                               const float* a_src, const float* a_dst, const float* alpha, float* dh, int64_t lddh,
+                               int64_t bsdh, float* d_att_src, float* d_att_dst, float* d_bias, int32_t accumulate,
+                               int32_t B, int32_t H, int32_t C, void* ws, size_t ws_bytes, gcl_stream_t stream) {
+  GCL_CHECK_ARG(tab, "gat_bwd_tab: null row table");
+  GCL_CHECK_ARG((int64_t)B * bsh * 4 < ((int64_t)1 << 32), "gat_bwd_tab: h must stay below 4 GiB (32-bit row offsets)");
+  return gat_bwd_impl(g, dy, lddy, bsdy, h, ldh, bsh, tab, att_src, att_dst, a_src, a_dst, alpha, dh, lddh, bsdh, d_att_src,
+                      d_att_dst, d_bias, accumulate, B, H, C, ws, ws_bytes, stream);
 }
 
 extern "C" int gcl_gat_alpha_to_edge_order(const gcl_graph_t* g, const float* alpha_slots, float* alpha_edges,

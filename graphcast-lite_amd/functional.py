@@ -126,10 +126,11 @@ _LN_COLSUM = os.environ.get("GCL_NO_LN_COLSUM", "0") in ("0", "")
 _ROWS_OUT = os.environ.get("GCL_NO_ROWS_OUT", "0") in ("0", "")
 
 
-def _lat_first_layer_bwd(lat, enc3, dz3, W, dW, acc_dw: bool, want_dx: bool):
-    """Dense backward of a GCN stack's first layer whose input was read through a LatSource: dz3 [B, M, D'] is the
-    gradient of the layer's pre-aggregation rows (A^T dp).  Returns the gradient of the encoder output [B, ne, D] (or
-    None when the shared landing buffer took it / no gradient is wanted); dW is written / accumulated in place."""
+def _lat_first_layer_bwd(lat, enc3, dz3, W, dW, acc_dw: bool, want_dx: bool, Pc=None):
+    """Dense backward of a first processor layer whose input was read through a LatSource: dz3 [B, M, D'] is the
+    gradient of the layer's transformed mesh rows (GCN: A^T dp, GAT: dh).  Returns the gradient of the encoder output
+    [B, ne, D] (or None when the shared landing buffer took it / no gradient is wanted); dW is written / accumulated in
+    place.  Pc: the compact encoder rows [B, Md + r, D] when the forward already copied them."""
     _, _, inv_a, inv_fold = lat.maps
     B, ne, D = enc3.shape
     G, Md, r = lat.G, lat.Md, lat.r
@@ -143,7 +144,8 @@ def _lat_first_layer_bwd(lat, enc3, dz3, W, dW, acc_dw: bool, want_dx: bool):
     if r > 0:
         tmp = hip.gather2_rows(dz3, inv_fold, None, None, B * r, B, sum_batch=True)
         hip.copy_rows(tmp.view(B, r, Fo), dzc[:, Md:])
-    Pc = hip.copy_rows(enc3[:, G:, :], torch.empty(B, nc, D, dtype=torch.float32, device=dz3.device))  # the encoder rows behind the mesh latents
+    if Pc is None:  # the encoder rows behind the mesh latents
+        Pc = hip.copy_rows(enc3[:, G:, :], torch.empty(B, nc, D, dtype=torch.float32, device=dz3.device))
     land = lat.landing
     shared = land is not None and land.buf is not None
     if not want_dx:
@@ -175,6 +177,20 @@ class LatSource:
 
     def __init__(self, tab, maps, M: int, G: int, Md: int, r: int, landing=None):
         self.tab, self.maps, self.M, self.G, self.Md, self.r, self.landing = tab, maps, M, G, Md, r, landing
+        self._compact = {}
+
+    def compact_tab(self, ne: int):
+        """The table relative to the COMPACT rows enc[:, G:, :] copied to [B, Md + r, D] (a GAT layer transforms those
+        first): own rows shift by G, flat row b' * ne + G + k becomes b' * (Md + r) + k."""
+        t = self._compact.get(ne)
+        if t is None:
+            tab = self.tab.to(torch.int64)
+            f = -tab - 1
+            bq = torch.div(f, ne, rounding_mode="floor")
+            flat_c = bq * (self.Md + self.r) + (f - bq * ne - self.G)
+            t = torch.where(tab >= 0, tab - self.G, -flat_c - 1).to(torch.int32).contiguous()
+            self._compact[ne] = t
+        return t
 
 
 class GCNStackFn(torch.autograd.Function):
@@ -362,10 +378,28 @@ class GATLayerFn(torch.autograd.Function):
         Cc = W.shape[0] // H
         sl = slope.detach() if slope is not None else None
         act = getattr(owner, "_in_act", None)  # None: PReLU when a slope is given
-        h = hip.linear_fwd(x3.view(B * n, -1), W.detach(), None, sl, act=act).view(B, n, H * Cc)
+        lat = getattr(owner, "_lat_src", None)
+        ctx.lat = ctx.tab = None
+        if lat is not None:
+            # x is the encoder output [B, ne, D] (LatSource): only its compact mesh rows are transformed, the attention
+            # kernels read the transformed rows through the table - no [B, M, D] latents, no [B, M, H*C] transform
+            owner._lat_src = None
+            assert sl is None, "a LatSource feeds the first layer of a stack (no input activation)"
+            if not x3.is_contiguous():
+                x3 = x3.contiguous()
+            ne, D = x3.shape[1], x3.shape[2]
+            nc = lat.Md + lat.r
+            Pc = hip.copy_rows(x3[:, lat.G:, :], torch.empty(B, nc, D, dtype=torch.float32, device=x3.device))
+            h = hip.linear_fwd(Pc.view(B * nc, D), W.detach(), None, None, act=act).view(B, nc, H * Cc)
+            ctx.lat, ctx.tab, ctx.enc_shape = lat, lat.compact_tab(ne), x3.shape
+            x3 = Pc
+            if lat.landing is not None:
+                lat.landing.mesh_pending = True
+        else:
+            h = hip.linear_fwd(x3.view(B * n, -1), W.detach(), None, sl, act=act).view(B, n, H * Cc)
         ctx.act = act
         y, a_s, a_d, alpha = hip.gat_fwd(graph, h, att_src.detach().reshape(-1), att_dst.detach().reshape(-1),
-                                         bias.detach(), H, Cc)
+                                         bias.detach(), H, Cc, tab=ctx.tab)
         alpha_edges = hip.gat_alpha_edge_order(graph, alpha[0], H) if want_alpha else torch.empty(0, device=x3.device)
         ctx.owner, ctx.graph, ctx.H, ctx.Cc, ctx.squeeze = owner, graph, H, Cc, squeeze
         ctx.x3, ctx.h, ctx.a_s, ctx.a_d, ctx.alpha = x3, h, a_s, a_d, alpha
@@ -389,13 +423,19 @@ class GATLayerFn(torch.autograd.Function):
             t_as, t_ad = torch.zeros_like(att_src), torch.zeros_like(att_dst)
             t_b = torch.zeros_like(bias) if G.dst[4] is not None else None
             dh = hip.gat_bwd(graph, dy3, ctx.h, att_src.detach().reshape(-1), att_dst.detach().reshape(-1), ctx.a_s,
-                             ctx.a_d, ctx.alpha, t_as.view(-1), t_ad.view(-1), t_b, False, H, Cc)
+                             ctx.a_d, ctx.alpha, t_as.view(-1), t_ad.view(-1), t_b, False, H, Cc, tab=ctx.tab)
             for dst, t, a in ((G.dst[2], t_as, G.acc[2]), (G.dst[3], t_ad, G.acc[3]), (G.dst[4], t_b, G.acc[4])):
                 if dst is not None:
                     dst.add_(t) if a else dst.copy_(t)
         else:
             dh = hip.gat_bwd(graph, dy3, ctx.h, att_src.detach().reshape(-1), att_dst.detach().reshape(-1), ctx.a_s,
-                             ctx.a_d, ctx.alpha, d_as.view(-1), d_ad.view(-1), G.dst[4], True, H, Cc)
+                             ctx.a_d, ctx.alpha, d_as.view(-1), d_ad.view(-1), G.dst[4], True, H, Cc, tab=ctx.tab)
+        if ctx.lat is not None:
+            # fold dh [B, M, H*C] back onto the compact rows and run the dense backward there (LatSource)
+            dW = G.dst[1] if G.dst[1] is not None else torch.zeros_like(W)
+            dx = _lat_first_layer_bwd(ctx.lat, torch.empty(ctx.enc_shape, device="meta"), dh, W.detach(), dW, G.acc[1],
+                                      ctx.needs_input_grad[0], Pc=ctx.x3)
+            return (dx, None, None, None, None) + G.out()
         dh2 = dh.view(B * n, -1)
         inp = ctx.x3.view(B * n, -1)
         sl = slope.detach() if slope is not None else None

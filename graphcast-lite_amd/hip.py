@@ -48,6 +48,10 @@ _SIGNATURES = {
     "gcl_gat_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
                               _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "gcl_gat_bwd_ws_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
+    "gcl_gat_fwd_tab": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "gcl_gat_bwd_tab": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
+                                  _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "gcl_gat_tab_ok": (C.c_int, [_vp, _i64, _i32, _i32]),
     "gcl_gat_alpha_to_edge_order": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "gcl_gat_prune": (C.c_int, [_vp, _vp, _f32, _vp, C.POINTER(_i64), _vp, _sz, _vp]),
     "gcl_gat_prune_ws_bytes": (_sz, [_i64]),
@@ -524,30 +528,51 @@ def colsum(x, out, accumulate: bool):
     return out
 
 
-def gat_fwd(graph: Graph, h3, att_src, att_dst, bias, H, Cc, need_alpha=True):
+def gat_tab_ok(graph: Graph, H: int, Cc: int) -> bool:
+    """True when gat_fwd / gat_bwd can read the rows of h through a row table (one head, source-tile graph)."""
+    return bool(lib().gcl_gat_tab_ok(graph.handle, H * Cc, int(H), int(Cc)))
+
+
+def gat_fwd(graph: Graph, h3, att_src, att_dst, bias, H, Cc, need_alpha=True, tab=None):
+    """tab (int32 [graph.n]): h3 is [B, rows, H*C] and mesh row i of sample b is h3[b, tab[i]] or the flat row ~tab[i]."""
     B, n, HC = h3.shape
+    if tab is not None:
+        n = graph.n
+        assert h3.is_contiguous()
     dev = h3.device
     a_s = torch.empty(B, n, H, dtype=torch.float32, device=dev)
     a_d = torch.empty(B, n, H, dtype=torch.float32, device=dev)
     alpha = torch.empty(B, graph.e, H, dtype=torch.float32, device=dev) if need_alpha else None
     y = torch.empty(B, n, Cc, dtype=torch.float32, device=dev)
     tok = _probe_begin("gat_fwd", graph=graph, B=B, H=H, C=Cc, alpha=need_alpha)
-    _check(lib().gcl_gat_fwd(graph.handle, _p(h3), h3.stride(1), h3.stride(0), _p(att_src), _p(att_dst), _p(bias),
-                             _p(a_s), _p(a_d), _p(alpha), _p(y), Cc, n * Cc, B, H, Cc, _stream()))
+    if tab is not None:
+        _check(lib().gcl_gat_fwd_tab(graph.handle, _p(h3), h3.stride(1), h3.stride(0), _pi(tab), _p(att_src), _p(att_dst),
+                                     _p(bias), _p(a_s), _p(a_d), _p(alpha), _p(y), Cc, n * Cc, B, H, Cc, _stream()))
+    else:
+        _check(lib().gcl_gat_fwd(graph.handle, _p(h3), h3.stride(1), h3.stride(0), _p(att_src), _p(att_dst), _p(bias),
+                                 _p(a_s), _p(a_d), _p(alpha), _p(y), Cc, n * Cc, B, H, Cc, _stream()))
     _probe_end(tok)
     return y, a_s, a_d, alpha
 
 
-def gat_bwd(graph: Graph, dy3, h3, att_src, att_dst, a_s, a_d, alpha, d_att_src, d_att_dst, d_bias, accumulate, H, Cc):
+def gat_bwd(graph: Graph, dy3, h3, att_src, att_dst, a_s, a_d, alpha, d_att_src, d_att_dst, d_bias, accumulate, H, Cc, tab=None):
     B, n, HC = h3.shape
+    if tab is not None:
+        n = graph.n  # dh is dense [B, n, HC]: the gradient of the table-read rows
     dy3 = dy3.contiguous()
     dh = torch.empty(B, n, HC, dtype=torch.float32, device=h3.device)
     nb = lib().gcl_gat_bwd_ws_bytes(graph.e, n, B, H, Cc)
     ws = workspace(nb, h3.device)
     tok = _probe_begin("gat_bwd", graph=graph, B=B, H=H, C=Cc)
-    _check(lib().gcl_gat_bwd(graph.handle, _p(dy3), Cc, n * Cc, _p(h3), h3.stride(1), h3.stride(0), _p(att_src),
-                             _p(att_dst), _p(a_s), _p(a_d), _p(alpha), _p(dh), HC, n * HC, _p(d_att_src), _p(d_att_dst),
-                             _p(d_bias), 1 if accumulate else 0, B, H, Cc, ws.data_ptr(), ws.numel(), _stream()))
+    if tab is not None:
+        _check(lib().gcl_gat_bwd_tab(graph.handle, _p(dy3), Cc, n * Cc, _p(h3), h3.stride(1), h3.stride(0), _pi(tab), _p(att_src),
+                                     _p(att_dst), _p(a_s), _p(a_d), _p(alpha), _p(dh), HC, n * HC, _p(d_att_src),
+                                     _p(d_att_dst), _p(d_bias), 1 if accumulate else 0, B, H, Cc, ws.data_ptr(), ws.numel(),
+                                     _stream()))
+    else:
+        _check(lib().gcl_gat_bwd(graph.handle, _p(dy3), Cc, n * Cc, _p(h3), h3.stride(1), h3.stride(0), _p(att_src),
+                                 _p(att_dst), _p(a_s), _p(a_d), _p(alpha), _p(dh), HC, n * HC, _p(d_att_src), _p(d_att_dst),
+                                 _p(d_bias), 1 if accumulate else 0, B, H, Cc, ws.data_ptr(), ws.numel(), _stream()))
     _probe_end(tok)
     return dh
 

@@ -139,9 +139,10 @@ class GATConv(nn.Module):
         _glorot_(self.att_src)
         _glorot_(self.att_dst)
 
-    def _run(self, x, edge_index, slope, want_alpha, act=None):
-        g = _graphs.get(edge_index, _num_nodes(x), hip.GRAPH_GAT)
+    def _run(self, x, edge_index, slope, want_alpha, act=None, lat_src=None):
+        g = _graphs.get(edge_index, lat_src.M if lat_src is not None else _num_nodes(x), hip.GRAPH_GAT)
         self._in_act = act
+        self._lat_src = lat_src  # functional.LatSource (picked up by GATLayerFn): x is the encoder output
         y, alpha = GATLayerFn.apply(x, self, g, self.heads, want_alpha, slope, self.lin.weight, self.att_src,
                                     self.att_dst, self.bias)
         return y, alpha, g
@@ -402,7 +403,7 @@ class GraphLayer(nn.Module):
             if edge_attr is None:
                 raise ValueError("InteractionNet requires edge_attr (edge features)")
             return self.layers(x=X, edge_index=edge_index, edge_attr_raw=edge_attr)
-        lat_src = kwargs.get("_lat_src") if self.layer_type == GraphLayerType.ConvGCN else None
+        lat_src = kwargs.get("_lat_src") if self.layer_type in (GraphLayerType.ConvGCN, GraphLayerType.GATConv) else None
         n = lat_src.M if lat_src is not None else _num_nodes(X)  # with a LatSource X is the encoder output, the graph the mesh
         ln = self._final_ln()
         fuse_ln = ln is not None and ln.mode == "node"
@@ -429,7 +430,8 @@ class GraphLayer(nn.Module):
             slope, act = None, hip.ACT_NONE
             for layer in self.layers:
                 if isinstance(layer, GATConv):
-                    X, _, _ = layer._run(X, edge_index, slope, False, act)
+                    X, _, _ = layer._run(X, edge_index, slope, False, act, lat_src=lat_src)
+                    lat_src = None  # only the first conv reads the encoder output
                     # the next conv applies the shared activation while loading its input
                     slope = self._slope if self._slope is not None else self.const_slope
                     act = self.act_kind
@@ -799,6 +801,14 @@ class WeatherPrediction(nn.Module):
         if not self._lat_through_table or c.perm is None or self.processor.mlp is not None:
             return None
         gl = self.processor.graph_layer
+        if gl.layer_type == GraphLayerType.GATConv:
+            first = gl.layers[0]
+            if not isinstance(first, GATConv) or first.heads != 1 or enc_c.dim() != 3 or first.lin.weight.shape[1] != enc_c.shape[-1]:
+                return None
+            g = _graphs.get(self._processing_graph_tiled(), self._num_mesh_nodes, hip.GRAPH_GAT)
+            if not hip.gat_tab_ok(g, 1, first.lin.weight.shape[0]):
+                return None
+            return LatSource(f.tab, f.maps, self._num_mesh_nodes, self._num_grid_nodes, c.Md, f.r, land)
         if gl.layer_type != GraphLayerType.ConvGCN:
             return None
         convs = [m for m in gl.layers if isinstance(m, GCNConv)]

@@ -213,6 +213,21 @@ int gcl_gat_bwd(const gcl_graph_t* g, const float* dy, int64_t lddy, int64_t bsd
                 float* d_bias, int32_t accumulate, int32_t B, int32_t H, int32_t C,
                 void* ws, size_t ws_bytes, gcl_stream_t stream);
 size_t gcl_gat_bwd_ws_bytes(int64_t e_prime, int32_t n, int32_t B, int32_t H, int32_t C);
+/* The same two calls with the rows of h read THROUGH a row table (the stage split of src/models.py:837-838 folded
+ * into the first processor layer: only the compact rows are transformed, functional.LatSource): row i of sample b is
+ * row tab[i] of sample b of h when tab[i] >= 0, the batch-invariant flat row ~tab[i] of h otherwise; a_src / a_dst /
+ * alpha / y / dh stay dense [B, n, ..].  One head on a source-tile graph (gcl_gat_tab_ok returns 1), else
+ * GCL_EUNSUPPORTED.  gcl_gat_bwd_tab's dh is the gradient of the table-read rows; the caller folds it back. */
+int gcl_gat_fwd_tab(const gcl_graph_t* g, const float* h, int64_t ldh, int64_t bsh, const int32_t* tab /*[n]*/,
+                    const float* att_src, const float* att_dst, const float* bias, float* a_src, float* a_dst,
+                    float* alpha, float* y, int64_t ldy, int64_t bsy, int32_t B, int32_t H, int32_t C,
+                    gcl_stream_t stream);
+int gcl_gat_bwd_tab(const gcl_graph_t* g, const float* dy, int64_t lddy, int64_t bsdy, const float* h, int64_t ldh,
+                    int64_t bsh, const int32_t* tab /*[n]*/, const float* att_src, const float* att_dst,
+                    const float* a_src, const float* a_dst, const float* alpha, float* dh, int64_t lddh, int64_t bsdh,
+                    float* d_att_src, float* d_att_dst, float* d_bias, int32_t accumulate, int32_t B, int32_t H,
+                    int32_t C, void* ws, size_t ws_bytes, gcl_stream_t stream);
+int gcl_gat_tab_ok(const gcl_graph_t* g, int64_t ldh, int32_t H, int32_t C);
 /* Re-order per-slot attention of ONE sample into PyG edge order: out[eperm[s]*H + k] = alpha[s*H + k]
  * (what SparseGATConv thresholds: src/models.py:136-149). */
 int gcl_gat_alpha_to_edge_order(const gcl_graph_t* g, const float* alpha_slots, float* alpha_edges,

@@ -619,6 +619,36 @@ def test_gat_fwd_source_tiles(hip, levels, C, B, monkeypatch):
         assert rel(d_as.cpu(), a_sr.grad.reshape(-1)) < 5e-5 and rel(d_ad.cpu(), a_dr.grad.reshape(-1)) < 5e-5
 
 
+@pytest.mark.parametrize("levels,C,B", [([3, 5], 64, 9), ([2, 4], 128, 3)])
+def test_gat_through_row_table(hip, levels, C, B):
+    """gcl_gat_fwd_tab / gcl_gat_bwd_tab: the rows of h are read through a row table (own rows of a compact tensor or
+    batch-invariant flat rows).  Everything must be BIT-equal to the same calls on the materialised [B, n, C] rows."""
+    g = build_graphs(experiment("baseline", mesh_levels=levels))
+    n = g["M"]
+    ei_t, order, pos = _tiled(g)
+    G = hip.Graph(ei_t, n, hip.GRAPH_GAT)
+    assert hip.gat_tab_ok(G, 1, C)
+    nc = n // 3 + 11
+    gen = torch.Generator().manual_seed(7)
+    hc = rnd(B, nc, C, seed=1)
+    own = torch.rand(n, generator=gen) < 0.2
+    tab = torch.where(own, torch.randint(0, nc, (n,), generator=gen), -torch.randint(0, B * nc, (n,), generator=gen) - 1).to(torch.int32)
+    h = torch.where(own[None, :, None], hc[:, tab.clamp(min=0).long()], hc.reshape(B * nc, C)[(-tab.long() - 1).clamp(min=0)][None]).contiguous()
+    a_s, a_d, b = rnd(C, seed=3, scale=0.3).to(DEV), rnd(C, seed=4, scale=0.3).to(DEV), rnd(C, seed=5).to(DEV)
+    ref = hip.gat_fwd(G, h.to(DEV), a_s, a_d, b, 1, C)
+    got = hip.gat_fwd(G, hc.to(DEV), a_s, a_d, b, 1, C, tab=tab.to(DEV))
+    for r_, g_ in zip(ref, got):
+        assert torch.equal(r_, g_)
+    dy = rnd(B, n, C, seed=6).to(DEV)
+    outs = []
+    for hh, tt in ((h.to(DEV), None), (hc.to(DEV), tab.to(DEV))):
+        d_as, d_ad, d_b = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        dh = hip.gat_bwd(G, dy, hh, a_s, a_d, ref[1], ref[2], ref[3], d_as, d_ad, d_b, False, 1, C, tab=tt)
+        outs.append((dh, d_as, d_ad, d_b))
+    for r_, g_ in zip(outs[0], outs[1]):
+        assert torch.equal(r_, g_)
+
+
 def test_gat_unsupported_geometry_is_reported(hip):
     g = build_graphs(experiment("baseline", mesh_levels=[0]))
     G = hip.Graph(g["proc"], 12, hip.GRAPH_GAT)
