@@ -571,6 +571,12 @@ __global__ __launch_bounds__(256) void gat_halo_fwd_kernel(const int32_t* __rest
           const int row = tile * T + wave * (T / NW) + sub + it * RPW;
           own[TAB ? it : 0] = tab[row < n ? row : n - 1];
         }
+        // the table entries arrive HERE, inside the new-tile branch: left to hipcc, the wait for these vector loads sits
+        // at the join and every item then waits for the previous item's stores before it may issue its DMA
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(own[TAB ? it : 0]));
+#pragma unroll
+        for (int q = 0; q < MAXPW; ++q) asm volatile("" : "+v"(jj[q]));
       }
     }
     const char* Hc = reinterpret_cast<const char*>(Hf + (int64_t)b * bsh);
@@ -715,7 +721,7 @@ __global__ __launch_bounds__(256) void gat_halo_fwd_kernel(const int32_t* __rest
 // Rows with more than 16 edges take the CSR loop; heavy rows (> 64) keep such graphs on the per-edge kernels.
 // ---------------------------------------------------------------------------------------------------------
 template <int LPR, int MAXPW, bool TAB = false>
-__global__ __launch_bounds__(256) void gat_halo_bwd_dst_kernel(
+__global__ __launch_bounds__(256, (TAB && LPR == 16) ? 4 : 1) void gat_halo_bwd_dst_kernel(
     const int32_t* __restrict__ list, const int32_t* __restrict__ cnt, const int2* __restrict__ rec,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ opos, int32_t smax, const float* __restrict__ dY,
     int64_t lddy, int64_t bsdy, const float* __restrict__ Hf, int64_t ldh, int64_t bsh, const float* __restrict__ a_s,
@@ -791,6 +797,12 @@ __global__ __launch_bounds__(256) void gat_halo_bwd_dst_kernel(
           const int row = tile * T + wave * (T / NW) + sub + it * RPW;
           own[TAB ? it : 0] = tab[row < n ? row : n - 1];
         }
+        // the table entries arrive HERE, inside the new-tile branch: left to hipcc, the wait for these vector loads sits
+        // at the join and every item then waits for the previous item's stores before it may issue its DMA
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(own[TAB ? it : 0]));
+#pragma unroll
+        for (int q = 0; q < MAXPW; ++q) asm volatile("" : "+v"(jj[q]));
       }
     }
     const char* Hc = reinterpret_cast<const char*>(Hf + (int64_t)b * bsh);
