@@ -155,6 +155,35 @@ def test_folded_invariant_rows_equal_separate_pass(levels, B):
         assert d <= 1e-5 * float(gf[n_].double().norm()) + 1e-7 * gn, n_
 
 
+@pytest.mark.parametrize("name,levels,B", [("baseline", [3, 5], 9), ("attention", [3, 5], 9), ("baseline", [2, 4], 3)])
+def test_latents_through_row_table_equal_materialised(name, levels, B):
+    """The first processor layer reads the mesh latents from the encoder output through a row table and runs its dense
+    backward on the compact rows (functional.LatSource; GCNConv and one-head GATConv processors).  Against the same
+    model with the latents gathered into [B, M, D] first (GCL_NO_LAT_TABLE): the prediction is bit-identical, the
+    gradients agree to summation order."""
+    from graphcast_lite_amd.train import batch_loss
+
+    cfg, m, o = make_pair(name, levels)
+    X, y = data(cfg, m._num_grid_nodes, B)
+    assert m._compact_eligible() and m._fold_invariant_rows and m._lat_through_table
+    out_t = m(X.to(DEV))
+    c = m._compact
+    f = c.fold[B]
+    enc_probe = torch.empty(B, f.ne, cfg.pipeline.encoder.gcn.output_dim, device=DEV)
+    assert m._lat_source(c, f, enc_probe, None) is not None, "the row-table path did not engage on this config"
+    batch_loss(m, X.to(DEV), y.to(DEV)).backward()
+    gt = {n_: p.grad.clone() for n_, p in m.named_parameters()}
+    m.zero_grad()
+    m._lat_through_table = False
+    out_g = m(X.to(DEV))
+    batch_loss(m, X.to(DEV), y.to(DEV)).backward()
+    assert torch.equal(out_t, out_g)
+    gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in gt.values())))
+    for n_, p in m.named_parameters():
+        d = float((p.grad.double() - gt[n_].double()).norm())
+        assert d <= 1e-5 * float(gt[n_].double().norm()) + 1e-7 * gn, n_
+
+
 def test_graph_mode_layernorm_model():
     """A pipeline whose MLP and processor use layer_norm_mode="graph" (SURVEY.md §8a row 9)."""
     from graphcast_lite_amd.models import WeatherPrediction
