@@ -729,6 +729,31 @@ class WeatherPrediction(nn.Module):
         # the same two maps as ONE row table for consumers that read the mesh latents through it (gcl_gcn_layer_fwd_tab):
         # entry >= 0: row of the sample's own encoder output, entry < 0: ~(flat row of the batch-invariant list)
         f.tab = torch.where(f.maps[0] >= 0, f.maps[0], -f.maps[1] - 1).to(torch.int32).contiguous()
+        # The encoder's MLP is row-wise and EVERY mesh row enters it as [0 | static] (src/models.py:792-801): the Md
+        # batch-dependent mesh rows differ between samples only after the encoder's first GCNConv.  So the MLP runs on
+        # [G grid | r folded invariant | rd = ceil(Md / B) folded dependent] rows per sample (2209 instead of 4118 at
+        # 64x32, B = 64) and the conv stack's input [G | Md | r] is put together from its output: grid and invariant rows
+        # from the sample's own rows, a dependent row from the flat list (shared by all samples; its gradient is the batch
+        # sum) - the op MeshLatFn already is, with these maps.
+        rd = -(-Md // B) if Md > 0 else 0
+        f.rd, f.nm = rd, G + r + rd
+        x_dep = torch.zeros(B * rd, Cdyn + Cs, device=device)
+        x_dep[:Md, Cdyn:] = c.mstat_dep.to(device)
+        f.x_tail2 = torch.cat([f.x_fold, x_dep.view(B, rd, Cdyn + Cs)], dim=1).contiguous()
+        f.mstat2 = torch.zeros(r + rd, Cs, device=device)
+        ea = torch.full((ne,), -1, dtype=torch.int64)
+        ea[:G] = torch.arange(G)
+        ea[G + Md:] = G + torch.arange(r)
+        eb = torch.full((ne,), -1, dtype=torch.int64)
+        d = torch.arange(Md)
+        if rd > 0:
+            eb[G: G + Md] = (d // rd) * f.nm + G + r + (d % rd)
+        einv_a = torch.full((G + r,), -1, dtype=torch.int64)
+        einv_a[:G] = torch.arange(G)
+        einv_a[G:] = G + Md + torch.arange(r)
+        einv_f = torch.full((B * rd,), -1, dtype=torch.int64)
+        einv_f[:Md] = G + d
+        f.maps_e = (i32(ea), i32(eb), i32(einv_a), i32(einv_f))
         # decoder-input maps: the encoder output now has ne rows per sample, the folded ones feed nothing there
         dinv_a = torch.cat([c.maps_dec[2], torch.full((r,), -1, dtype=torch.int32, device=device)]).contiguous()
         f.maps_dec = (c.maps_dec[0], c.maps_dec[1], dinv_a, c.maps_dec[3])
@@ -748,8 +773,14 @@ class WeatherPrediction(nn.Module):
             # (every mesh node has grid senders, e.g. 512x256) the same path runs with r = 0, so the two gradient
             # consumers of the encoder output still share one landing buffer instead of autograd adding two full tensors
             f = c.fold.get(B) or self._fold_setup(c, B, X3.device)
-            x_c = AssembleFn.apply(X3, self.init_grid_features, f.mstat, f.x_fold if f.r > 0 else None)  # [B, G+Md+r, C]
-            enc_c = self.encoder.forward(X=x_c, edge_index=c.enc_graph)             # [B, G+Md+r, D]
+            if self._mlp_on_folded_rows and self.encoder.mlp is not None and f.rd > 0:
+                x_m = AssembleFn.apply(X3, self.init_grid_features, f.mstat2, f.x_tail2)   # [B, G+r+rd, C]
+                h_m = self.encoder.mlp(X=x_m)                                              # [B, G+r+rd, D']
+                x_g = MeshLatFn.apply(h_m, f.maps_e, f.ne, G + f.r, f.rd, None)            # [B, G+Md+r, D']
+                enc_c = self.encoder.graph_layer(X=x_g, edge_index=c.enc_graph)            # [B, G+Md+r, D]
+            else:
+                x_c = AssembleFn.apply(X3, self.init_grid_features, f.mstat, f.x_fold if f.r > 0 else None)  # [B, G+Md+r, C]
+                enc_c = self.encoder.forward(X=x_c, edge_index=c.enc_graph)         # [B, G+Md+r, D]
             land = GradLanding(G) if kwargs.pop("_landing", False) and self._grad_landing else None
             lat_src = self._lat_source(c, f, enc_c, land)
             if lat_src is None:
@@ -794,6 +825,7 @@ class WeatherPrediction(nn.Module):
         return out, grid_lat, processed
 
     _lat_through_table = os.environ.get("GCL_NO_LAT_TABLE", "0") in ("0", "")
+    _mlp_on_folded_rows = os.environ.get("GCL_NO_MLP_FOLD", "0") in ("0", "")
 
     def _lat_source(self, c, f, enc_c, land):
         """functional.LatSource when the processor's first layer can read the mesh latents through the row table
