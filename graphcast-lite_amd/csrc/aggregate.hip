@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void agg_kernel(const int32_t* __restrict__ ro
                                                   int64_t ldh, int64_t bsh, const float* __restrict__ bias,
                                                   float* __restrict__ Y, int64_t ldy, int64_t bsy, int32_t n,
                                                   int32_t B, int32_t F, int32_t nRB, int32_t xcd_map,
-                                                  int32_t nt_store) {
+                                                  int32_t nt_store, const int32_t* __restrict__ order16) {
   constexpr int RPW = 64 / LPR;
   constexpr int EL = LPR < gcl::kEll ? LPR : gcl::kEll;  // ELL entries a lane group can hold
   static_assert(EW <= EL, "ELL width exceeds the lanes of a row group");
@@ -53,6 +53,10 @@ __global__ __launch_bounds__(256) void agg_kernel(const int32_t* __restrict__ ro
     rb = bid % nRB;
   }
   if (b >= B) return;
+  if (order16) {  // the k-th block runs the rows of the k-th 16-row group of the graph's processing order (common.h)
+    constexpr int RPB = RPW * 4 * ITER, K = 16 / RPB;  // launched only with RPB <= 16
+    rb = order16[rb / (K > 0 ? K : 1)] * (K > 0 ? K : 1) + rb % (K > 0 ? K : 1);
+  }
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int sub = lane / LPR;
@@ -503,6 +507,8 @@ struct AggArgs {
   const float *w, *ew;
   int ell_width, n_heavy;
   const gcl_halo* halo;  // [2]: T = 64, T = 32 (T == 0: not built)
+  const int32_t* order16 = nullptr;  // processing order of 16-row groups (common.h), or nullptr
+  int32_t n_order16 = 0;
 };
 
 // Source-tile path: returns GCL_OK after launching, or -1 when this call is not eligible (agg_kernel runs instead).
@@ -597,14 +603,16 @@ int launch_agg(const AggArgs& ga, const float* h, int64_t ldh, int64_t bsh, cons
   // near-diagonal bipartite graphs with two (next batch's metadata prefetched)
   const int iter = (iter_env == 1 || iter_env == 2 || iter_env == 4 || iter_env == 8) ? iter_env
                                                                                        : (ewidth >= 4 ? 1 : 2);
-  const int32_t nRB = (int32_t)gcl::cdiv(n, RPW * 4 * iter);
+  int32_t nRB = (int32_t)gcl::cdiv(n, RPW * 4 * iter);
+  if (ga.order16 && RPW * 4 * iter <= 16) nRB = ga.n_order16 * (16 / (RPW * 4 * iter));  // whole 16-row groups (rows >= n are masked)
   const int xcd_map = B >= gcl::kNumXCD ? 1 : 0;
   const int64_t nb = xcd_map ? (int64_t)gcl::kNumXCD * gcl::cdiv(B, gcl::kNumXCD) * nRB : (int64_t)B * nRB;
   GCL_CHECK_ARG(nb < (int64_t)INT32_MAX, "aggregate: grid too large");
   dim3 grid((unsigned)nb), block(256);
+  const int32_t* order16 = (RPW * 4 * iter <= 16) ? ga.order16 : nullptr;
 #define GCL_AGG4(VL_, VS_, EW_, IT_)                                                                             \
   hipLaunchKernelGGL((agg_kernel<LPR, VL_, VS_, EW_, IT_>), grid, block, 0, st, ga.rowptr, ga.col, ga.w, ga.ecol, \
-                     ga.ew, h, ldh, bsh, bias, y, ldy, bsy, n, B, F, nRB, xcd_map, nt)
+                     ga.ew, h, ldh, bsh, bias, y, ldy, bsy, n, B, F, nRB, xcd_map, nt, order16)
 #define GCL_AGG3(VL_, VS_, EW_)              \
   do {                                       \
     if (iter == 8) GCL_AGG4(VL_, VS_, EW_, 8); \
@@ -648,6 +656,8 @@ extern "C" int gcl_aggregate(const gcl_graph_t* g, int32_t transpose, const floa
   ga.ecol = transpose ? g->tecol : g->ecol;
   ga.ew = transpose ? g->tew : g->ew;
   ga.ell_width = transpose ? g->tell_width : g->ell_width;
+  ga.order16 = g->order16[transpose ? 1 : 0];
+  ga.n_order16 = g->n_order16;
   ga.heavy = transpose ? g->theavy : g->heavy;
   ga.n_heavy = transpose ? g->n_theavy : g->n_heavy;
   ga.halo = g->halo[transpose ? 1 : 0];

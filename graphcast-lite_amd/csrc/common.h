@@ -114,6 +114,12 @@ struct gcl_graph {
   int32_t n_heavy = 0, n_theavy = 0;
   // source-tile layouts: [direction: 0 forward, 1 transpose][0: T = 64, 1: T = 32]; T == 0 when not built
   gcl_halo halo[2][2];
+  // Processing order of the per-edge kernels on large graphs: order16[d][k] = the k-th 16-row group to be processed.
+  // A group is placed right after the LAST group it reads from (self-loops aside), so on the bipartite encoder /
+  // decoder graphs a block of mesh rows runs while the grid rows it gathers are still in the XCD's L2 (and the other
+  // way round for the transposed graph); nullptr on graphs small enough for the L2 anyway.  [0] forward, [1] transpose.
+  int32_t* order16[2] = {nullptr, nullptr};
+  int32_t n_order16 = 0;
   // host copy of the PyG-order edge list with loops (for export / prune)
   int64_t* h_edges = nullptr;  // [2, e]
 };

@@ -228,8 +228,32 @@ bool build_halo_host(const std::vector<int32_t>& rp, const std::vector<int32_t>&
 }
 }  // namespace
 
+namespace {
+// see common.h, gcl_graph::order16
+std::vector<int32_t> build_order16(const std::vector<int32_t>& rp, const std::vector<int32_t>& cl, int32_t n) {
+  const int32_t ng = (n + 15) / 16;
+  std::vector<int64_t> key((size_t)ng);
+  bool moved = false;
+  for (int32_t gi = 0; gi < ng; ++gi) {
+    int32_t last = -1;
+    for (int32_t r = gi * 16; r < std::min(n, gi * 16 + 16); ++r)
+      for (int32_t e = rp[r]; e < rp[r + 1]; ++e)
+        if (cl[e] != r) last = std::max(last, cl[e] / 16);
+    if (last < 0) last = gi;  // only self-loops: stays where it is
+    moved |= last != gi;
+    key[(size_t)gi] = (int64_t)last * ng + gi;  // after group `last`, ties in row order
+  }
+  std::vector<int32_t> order((size_t)ng);
+  for (int32_t gi = 0; gi < ng; ++gi) order[(size_t)gi] = gi;
+  if (moved) std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key[(size_t)a] < key[(size_t)b]; });
+  return order;
+}
+}  // namespace
+
 extern "C" void gcl_graph_destroy(gcl_graph_t* g) {
   if (!g) return;
+  for (int d = 0; d < 2; ++d)
+    if (g->order16[d]) (void)hipFree(g->order16[d]);
   for (int d = 0; d < 2; ++d)
     for (int t = 0; t < 2; ++t) {
       void* hp[] = {g->halo[d][t].list, g->halo[d][t].cnt, g->halo[d][t].rec, g->halo[d][t].opos};
@@ -372,6 +396,19 @@ extern "C" int gcl_graph_create(const int64_t* ei, int64_t E, int32_t n, int32_t
       H.ntiles = hh.ntiles;
       H.smax = hh.smax;
     }
+  // processing order of the per-edge kernels: only where one sample's rows cannot sit in an XCD's 4 MiB L2 anyway
+  // (>= 32 Ki rows: 16 MB at 128 channels) and the graph has no source-tile layout
+  {
+    static const int ord_env = [] { const char* e = getenv("GCL_AGG_ORDER"); return e ? atoi(e) : 1; }();
+    if (!rc && ord_env && n >= 32768) {
+      for (int d = 0; d < 2 && !rc; ++d) {
+        if (g->halo[d][0].T) continue;
+        const std::vector<int32_t> ord = d == 0 ? build_order16(rowptr, col, n) : build_order16(trowptr, tcol, n);
+        rc = upload(&g->order16[d], ord.data(), ord.size());
+      }
+      g->n_order16 = (n + 15) / 16;
+    }
+  }
   if (rc) {
     gcl_graph_destroy(g);
     return rc;
