@@ -46,12 +46,16 @@ __device__ __forceinline__ void store4(float* p, int c0, int F, bool vec, float 
 // y = (x - mean) * rstd * gamma + beta ; stats[row] = (mean, rstd)
 // V: every row access is a clean 16-byte one (compile-time, so the compiler emits dwordx4 instead of
 // merging the vector and the scalar path into dwordx3 + dword accesses)
-template <int LPR, bool V>
+// MAP: the output goes through a row map - row (b, i) of the [B][n_per] row space is written to
+// Y[b * bsy + pos[i] * ldy] when pos[i] >= 0 and not at all otherwise (a LayerNorm whose output is only consumed through a
+// row gather writes the gathered rows straight into the consumer's input: src/models.py:860-862 for the processor).
+template <int LPR, bool V, bool MAP = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ X, int64_t ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, float* __restrict__ Y, int64_t ldy,
                                                      float* __restrict__ stats, int64_t rows, int32_t F, int32_t vx,
-                                                     int32_t vy) {
+                                                     int32_t vy, const int32_t* __restrict__ pos = nullptr,
+                                                     int64_t bsy = 0, int32_t n_per = 1) {
   if (V) vx = vy = 1;
   constexpr int RPB = (64 / LPR) * 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -68,9 +72,24 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ X
     const float mean = group_sum<LPR>(x0 + x1 + x2 + x3) * invF;
     const float d0 = (c0 < F) ? x0 - mean : 0.f, d1 = (c0 + 1 < F) ? x1 - mean : 0.f;
     const float d2 = (c0 + 2 < F) ? x2 - mean : 0.f, d3 = (c0 + 3 < F) ? x3 - mean : 0.f;
-    const float var = group_sum<LPR>(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * invF;
+    float sq;
+    {
+      // products and sums rounded separately: left to the compiler, the plain and the mapped instantiation contract
+      // this expression differently (fused multiply-adds in one, packed multiplies + adds in the other) and their
+      // statistics differ in the last bit
+#pragma clang fp contract(off)
+      const float q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2, q3 = d3 * d3;
+      sq = (q0 + q1) + (q2 + q3);
+    }
+    const float var = group_sum<LPR>(sq) * invF;
     const float rstd = 1.0f / sqrtf(var + eps);
-    if (c0 < F)
+    if (MAP) {
+      const int64_t bq = row / n_per;
+      const int pj = pos[(int)(row - bq * n_per)];
+      if (c0 < F && pj >= 0)
+        store4(Y + bq * bsy + (int64_t)pj * ldy + c0, c0, F, vy, d0 * rstd * g0 + b0, d1 * rstd * g1 + b1,
+               d2 * rstd * g2 + b2, d3 * rstd * g3 + b3);
+    } else if (c0 < F)
       store4(Y + row * ldy + c0, c0, F, vy, d0 * rstd * g0 + b0, d1 * rstd * g1 + b1, d2 * rstd * g2 + b2,
              d3 * rstd * g3 + b3);
     if (l == 0 && stats) {
@@ -228,10 +247,35 @@ extern "C" int gcl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
 #define CALL(L)                                                                                                  \
   if (vx && vy)                                                                                                  \
     hipLaunchKernelGGL((ln_fwd_kernel<L, true>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, ldx,  \
-                       gamma, beta, eps, y, ldy, stats, rows, F, vx, vy);                                        \
+                       gamma, beta, eps, y, ldy, stats, rows, F, vx, vy, (const int32_t*)nullptr, (int64_t)0, 1); \
   else                                                                                                           \
     hipLaunchKernelGGL((ln_fwd_kernel<L, false>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, ldx, \
-                       gamma, beta, eps, y, ldy, stats, rows, F, vx, vy)
+                       gamma, beta, eps, y, ldy, stats, rows, F, vx, vy, (const int32_t*)nullptr, (int64_t)0, 1)
+  GCL_DISPATCH_LPR(lpr, CALL)
+#undef CALL
+  GCL_CHECK_LAUNCH();
+  return GCL_OK;
+}
+
+extern "C" int gcl_layernorm_fwd_map(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                     float* y, int64_t ldy, int64_t bsy, const int32_t* pos, int32_t n_per, float* stats,
+                                     int64_t rows, int32_t F, gcl_stream_t stream) {
+  GCL_CHECK_ARG(x && gamma && beta && y && pos && stats, "layernorm_fwd_map: null argument");
+  GCL_CHECK_ARG(F >= 1 && F <= 256 && ldx >= F && ldy >= F, "layernorm_fwd_map: bad shape F=%d", F);
+  GCL_CHECK_ARG(n_per > 0 && rows % n_per == 0, "layernorm_fwd_map: rows must be B * n_per");
+  if (rows == 0) return GCL_OK;
+  const int lpr = lpr_for(F);
+  const int rpb = (64 / lpr) * 4;
+  int64_t nb = gcl::cdiv(rows, rpb);
+  if (nb > 8192) nb = 8192;
+  const int vx = vec_ok(x, ldx, F), vy = vec_store_ok(y, ldy, F) && (bsy % 4 == 0);
+#define CALL(L)                                                                                                        \
+  if (vx && vy)                                                                                                        \
+    hipLaunchKernelGGL((ln_fwd_kernel<L, true, true>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, ldx,  \
+                       gamma, beta, eps, y, ldy, stats, rows, F, vx, vy, pos, bsy, n_per);                             \
+  else                                                                                                                 \
+    hipLaunchKernelGGL((ln_fwd_kernel<L, false, true>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, ldx, \
+                       gamma, beta, eps, y, ldy, stats, rows, F, vx, vy, pos, bsy, n_per)
   GCL_DISPATCH_LPR(lpr, CALL)
 #undef CALL
   GCL_CHECK_LAUNCH();

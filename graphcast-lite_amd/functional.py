@@ -263,10 +263,6 @@ class GCNStackFn(torch.autograd.Function):
             cur = p
         ctx.akind, ctx.slope_t, ctx.pad_last = akind, slope_t, pad_last
         out, stats = cur, None
-        if has_ln:
-            o2, stats = hip.layernorm_fwd(cur.view(B * n, -1), params[-2].detach(), params[-1].detach(), eps)
-            out = o2.view(B, n, -1)
-        ctx.owner, ctx.graph, ctx.L, ctx.has_ln = owner, graph, L, has_ln
         ctx.land = getattr(owner, "_grad_src", None)
         if ctx.land is not None:
             owner._grad_src = None
@@ -274,6 +270,19 @@ class GCNStackFn(torch.autograd.Function):
                 ctx.land.proc_ready = True
             else:
                 ctx.land = None
+        if has_ln:
+            land = ctx.land
+            if land is not None and land.dec_buf is not None and cur.is_contiguous() and land.dec_buf.shape[2] == cur.shape[2]:
+                # the output is only consumed by the decoder-input gather: the rows it takes are written straight into
+                # the decoder's input, the others not at all (GradLanding.dec_buf); autograd sees a stride-0 token
+                stats = hip.layernorm_fwd_map(cur.view(B * n, -1), params[-2].detach(), params[-1].detach(), eps,
+                                              land.dec_buf, land.dec_map)
+                land.dec_filled = True
+                out = cur.new_zeros(()).expand(B, n, cur.shape[2])
+            else:
+                o2, stats = hip.layernorm_fwd(cur.view(B * n, -1), params[-2].detach(), params[-1].detach(), eps)
+                out = o2.view(B, n, -1)
+        ctx.owner, ctx.graph, ctx.L, ctx.has_ln = owner, graph, L, has_ln
         ctx.x3, ctx.ps, ctx.stats, ctx.params, ctx.squeeze = x3, ps, stats, params, squeeze
         ctx.n_rows, ctx.out_rows = n, (int(out_rows) if out_rows and out_rows < n else 0)
         if ctx.out_rows:
@@ -592,13 +601,22 @@ class Gather2Fn(torch.autograd.Function):
     def forward(ctx, a, b, maps, nd: int, B: int, landing=None):
         map_a, map_b, inv_a, inv_b = maps
         a3 = a.detach()
-        b3 = b.detach() if b is not None else None
         if not a3.is_contiguous():
             a3 = a3.contiguous()
+        ctx.maps, ctx.B, ctx.landing = maps, B, landing
+        ctx.sa, ctx.sb = a3.shape, (b.shape if b is not None else None)
+        if landing is not None and landing.dec_filled:
+            # the rows of source b are already in place (written by the producer's LayerNorm through the row map, b itself
+            # is a stride-0 token): only the head rows of source a are copied
+            landing.dec_filled = False
+            buf, landing.dec_buf = landing.dec_buf, None
+            hip.copy_rows(a3[:, : landing.head, :], buf[:, : landing.head, :])
+            return buf
+        if landing is not None:
+            landing.dec_buf = None
+        b3 = b.detach() if b is not None else None
         if b3 is not None and not b3.is_contiguous():
             b3 = b3.contiguous()
-        ctx.maps, ctx.B, ctx.landing = maps, B, landing
-        ctx.sa, ctx.sb = a3.shape, (b3.shape if b3 is not None else None)
         return hip.gather2_rows(a3, map_a, b3, map_b, nd, B)
 
     @staticmethod
@@ -643,6 +661,10 @@ class GradLanding:
         # gather's incoming gradient seen through a row map - the processor's LayerNorm backward reads it that way
         # (gcl_layernorm_bwd_map) instead of a zero-filled dense [B, M, D] tensor
         self.proc_ready, self.proc_src, self.proc_map = False, None, None
+        # third channel (forward): the decoder-input buffer [B, head + U, D], allocated by the model before the processor
+        # runs, and the map mesh row -> row of that buffer (or -1).  The processor's final LayerNorm writes the rows
+        # the decoder reads straight into it (gcl_layernorm_fwd_map) and the gather then only copies the head rows.
+        self.dec_buf, self.dec_map, self.dec_filled = None, None, False
 
 
 class MeshLatFn(torch.autograd.Function):

@@ -84,6 +84,7 @@ _SIGNATURES = {
                                    C.c_size_t, _vp]),
     "gcl_gcn_layer_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "gcl_gcn_layer_fwd_rows": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "gcl_layernorm_fwd_map": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i32, _vp]),
     "gcl_gcn_layer_fwd_tab": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "gcl_gcn_layer_fwd_tab_ok": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _i32, _i32]),
     "gcl_segment_reduce": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
@@ -474,6 +475,18 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
     _check(lib().gcl_layernorm_fwd(_p(x), _ld(x), _p(gamma), _p(beta), float(eps), _p(y), F, _p(stats), rows, F, _stream()))
     return y, stats
+
+
+def layernorm_fwd_map(x, gamma, beta, eps, out3, pos):
+    """LayerNorm of x [B * n, F] with row (b, i) written to out3[b, pos[i], :F] (pos[i] >= 0) and dropped otherwise;
+    returns the (mean, rstd) statistics of every row."""
+    rows, F = x.shape
+    n_per = pos.numel()
+    assert out3.stride(2) == 1 and rows % n_per == 0 and out3.shape[0] == rows // n_per
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+    _check(lib().gcl_layernorm_fwd_map(_p(x), _ld(x), _p(gamma), _p(beta), float(eps), _p(out3), out3.stride(1), out3.stride(0),
+                                       _pi(pos), n_per, _p(stats), rows, F, _stream()))
+    return stats
 
 
 def layernorm_bwd(dy, x, gamma, stats, dgamma, dbeta, accumulate: bool, colsum_dx=None, acc_colsum: bool = False,

@@ -806,6 +806,12 @@ class WeatherPrediction(nn.Module):
                                                edge_attr=self._processing_edge_features)
         else:
             pg = self._processing_graph_tiled() if c.perm is not None else self.processing_graph
+            if (land is not None and self._ln_into_decoder_input and self._latents_discarded
+                    and self.processor.graph_layer.layer_type == GraphLayerType.ConvGCN and not squeeze):
+                # the processor's output is only consumed by the decoder-input gather: its final LayerNorm writes the
+                # rows the decoder reads straight into the decoder's input (functional.GradLanding.dec_buf)
+                land.dec_buf = torch.empty(B, G + c.U, enc_c.shape[-1], dtype=torch.float32, device=enc_c.device)
+                land.dec_map = maps_dec[3]
             if lat_src is not None:
                 # the first GCNConv reads the mesh latents THROUGH the row table from the encoder output: they are never
                 # materialised, and its backward works on the compact rows (functional.GCNStackFn, LatSource)
@@ -826,6 +832,8 @@ class WeatherPrediction(nn.Module):
 
     _lat_through_table = os.environ.get("GCL_NO_LAT_TABLE", "0") in ("0", "")
     _mlp_on_folded_rows = os.environ.get("GCL_NO_MLP_FOLD", "0") in ("0", "")
+    _ln_into_decoder_input = os.environ.get("GCL_NO_LN_MAP", "0") in ("0", "")
+    _latents_discarded = False  # True only inside forward(): nobody sees the processor's output
 
     def _lat_source(self, c, f, enc_c, land):
         """functional.LatSource when the processor's first layer can read the mesh latents through the row table
@@ -891,4 +899,10 @@ class WeatherPrediction(nn.Module):
     def forward(self, X: torch.Tensor, attention_threshold=0.0, **kwargs):
         # only the prediction leaves this call, so the compact encoder output has exactly two gradient consumers and
         # they may share one gradient buffer (functional.GradLanding)
-        return self.forward_with_latents(X, attention_threshold, _landing=True, **kwargs)[0]
+        # ... and the processor's output itself is never seen by the caller, so its LayerNorm may write only the rows the
+        # decoder reads, straight into the decoder's input (the `processed` the inner call returns is then a zero token)
+        self._latents_discarded = True
+        try:
+            return self.forward_with_latents(X, attention_threshold, _landing=True, **kwargs)[0]
+        finally:
+            self._latents_discarded = False

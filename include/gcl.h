@@ -247,6 +247,12 @@ size_t gcl_gat_prune_ws_bytes(int64_t e_prime);
 int gcl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                       float* y, int64_t ldy, float* stats, int64_t rows, int32_t F,
                       gcl_stream_t stream);
+/* The same with the output written THROUGH a row map: row (b, i) of the [B][n_per] row space goes to
+ * y[b * bsy + pos[i] * ldy] when pos[i] >= 0 and nowhere otherwise (stats are written for every row).  The processor's
+ * final LayerNorm writes the rows the decoder reads straight into the decoder's input (src/models.py:860-862). */
+int gcl_layernorm_fwd_map(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, float* y,
+                          int64_t ldy, int64_t bsy, const int32_t* pos /*[n_per]*/, int32_t n_per, float* stats,
+                          int64_t rows, int32_t F, gcl_stream_t stream);
 int gcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                       const float* stats, float* dx, int64_t lddx, float* dgamma, float* dbeta,
                       int32_t accumulate, int64_t rows, int32_t F, void* ws, size_t ws_bytes,

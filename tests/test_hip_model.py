@@ -184,6 +184,32 @@ def test_latents_through_row_table_equal_materialised(name, levels, B):
         assert d <= 1e-5 * float(gt[n_].double().norm()) + 1e-7 * gn, n_
 
 
+def test_processor_layernorm_into_decoder_input_equals_gather():
+    """forward(): nobody sees the processor's output, so its final LayerNorm writes only the rows the decoder reads,
+    straight into the decoder's input (gcl_layernorm_fwd_map, functional.GradLanding.dec_buf) and the gather copies
+    just the grid rows.  Against the same model with the dense LayerNorm + gather: prediction bit-identical, gradients
+    identical too (the backward is the same code on the same saved tensors)."""
+    from graphcast_lite_amd.train import batch_loss
+
+    cfg, m, o = make_pair("baseline", [3, 5])
+    X, y = data(cfg, m._num_grid_nodes, 5)
+    assert m._ln_into_decoder_input and m._grad_landing
+    out_m = m(X.to(DEV))
+    batch_loss(m, X.to(DEV), y.to(DEV)).backward()
+    gm = {n_: p.grad.clone() for n_, p in m.named_parameters()}
+    m.zero_grad()
+    m._ln_into_decoder_input = False
+    out_g = m(X.to(DEV))
+    batch_loss(m, X.to(DEV), y.to(DEV)).backward()
+    assert torch.equal(out_m, out_g)
+    for n_, p in m.named_parameters():
+        assert torch.equal(p.grad, gm[n_]), n_
+    # a caller that DOES look at the processor's output gets the real rows, whatever the landing flag says
+    m._ln_into_decoder_input = True
+    _, _, processed = m.forward_with_latents(X.to(DEV), _landing=True)
+    assert float(processed.detach().abs().max()) > 0
+
+
 def test_graph_mode_layernorm_model():
     """A pipeline whose MLP and processor use layer_norm_mode="graph" (SURVEY.md §8a row 9)."""
     from graphcast_lite_amd.models import WeatherPrediction

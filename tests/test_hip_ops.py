@@ -502,6 +502,30 @@ def test_graphnorm(hip, B, n, F):
     assert rel(const[0], bt.detach().expand(5, F)) < 1e-6  # 0 / (0 + eps)
 
 
+@pytest.mark.parametrize("B,n,F,ldo", [(3, 500, 64, 64), (2, 77, 33, 36), (4, 1000, 128, 128)])
+def test_layernorm_fwd_through_row_map(hip, B, n, F, ldo):
+    """gcl_layernorm_fwd_map: row (b, i) is written to out[b, pos[i]] (pos[i] >= 0) and nowhere otherwise; statistics
+    for every row.  Bit-equal to the dense LayerNorm followed by the gather; untouched rows keep their content."""
+    gen = torch.Generator().manual_seed(3)
+    x, gm, bt = rnd(B * n, F, seed=1), rnd(F, seed=2), rnd(F, seed=3)
+    keep = torch.rand(n, generator=gen) < 0.45
+    nk = int(keep.sum())
+    head = 11
+    pos = torch.full((n,), -1, dtype=torch.int32)
+    pos[keep] = (head + torch.randperm(nk, generator=gen)).to(torch.int32)
+    y_ref, st_ref = hip.layernorm_fwd(x.to(DEV), gm.to(DEV), bt.to(DEV), 1e-5)
+    out = torch.full((B, head + nk, ldo), 7.0, device=DEV)
+    st = hip.layernorm_fwd_map(x.to(DEV), gm.to(DEV), bt.to(DEV), 1e-5, out, pos.to(DEV))
+    # (the two instantiations are separate compilations of the same expressions: equal to rounding, and bit-equal for the
+    # 16-byte-row widths the model uses - the folded-vs-separate model test relies on that)
+    y3 = y_ref.view(B, n, F)
+    if F % 4 == 0:
+        assert torch.equal(st, st_ref)
+        assert torch.equal(out[:, pos[keep].long(), :F], y3[:, keep])
+    assert rel(st, st_ref) < 1e-6 and rel(out[:, pos[keep].long(), :F], y3[:, keep]) < 1e-6
+    assert (out[:, :head] == 7.0).all() and (out[..., F:] == 7.0).all()
+
+
 @pytest.mark.parametrize("rows,F", [(1000, 64), (13, 33), (5000, 128)])
 def test_colsum(hip, rows, F):
     x = rnd(rows, F, seed=1)
