@@ -33,7 +33,7 @@ struct Walk3 {
 __global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__ x, const float* __restrict__ gs,
                                                        const float* __restrict__ ms, float* __restrict__ out,
                                                        int64_t ldo, int32_t B, int32_t G, int32_t M, int32_t Cdyn,
-                                                       int32_t Cs) {
+                                                       int32_t Cs, const float* __restrict__ tail, int32_t r) {
   const int C = Cdyn + Cs;
   const int64_t total = (int64_t)B * (G + M) * C;
   const int64_t stride = (int64_t)gridDim.x * 256;
@@ -44,6 +44,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__
     float v;
     if (i < G)
       v = c < Cdyn ? x[(b * G + i) * Cdyn + c] : gs[(int64_t)i * Cs + (c - Cdyn)];
+    else if (i >= G + M - r)  // per-sample tail rows, given whole
+      v = tail[(b * r + (i - (G + M - r))) * C + c];
     else
       v = c < Cdyn ? 0.f : ms[(int64_t)(i - G) * Cs + (c - Cdyn)];
     out[(b * (G + M) + i) * ldo + c] = v;
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void assemble4_kernel(const float* __restrict__ x, const float* __restrict__ gs,
                                                         const float* __restrict__ ms, float* __restrict__ out,
                                                         int64_t ldo, int32_t B, int32_t G, int32_t M, int32_t Cdyn,
-                                                        int32_t Cs) {
+                                                        int32_t Cs, const float* __restrict__ tail, int32_t r) {
   const int C4 = (Cdyn + Cs) >> 2;
   const int64_t total = (int64_t)B * (G + M) * C4;
   const int64_t stride = (int64_t)gridDim.x * 256;
@@ -69,6 +71,8 @@ __global__ __launch_bounds__(256) void assemble4_kernel(const float* __restrict_
       const int c = c0 + q;
       if (i < G)
         v[q] = c < Cdyn ? x[(b * G + i) * Cdyn + c] : gs[(int64_t)i * Cs + (c - Cdyn)];
+      else if (i >= G + M - r)
+        v[q] = tail[(b * r + (i - (G + M - r))) * (Cdyn + Cs) + c];
       else
         v[q] = c < Cdyn ? 0.f : ms[(int64_t)(i - G) * Cs + (c - Cdyn)];
     }
@@ -193,7 +197,8 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
 }
 
 // dst[b,i,:] = a[b, map_a[i], :] if map_a[i] >= 0, else b_[b, map_b[i], :] if map_b[i] >= 0, else 0.
-// A source with batch stride 0 is broadcast over the batch.  sum_batch: dst[0,i,:] = sum_b a[b, map_a[i], :].
+// A source with batch stride 0 is broadcast over the batch.  sum_batch: dst[0,i,:] = sum_b a[b, map_a[i], :];
+// sum_batch = R > 1 deals the nd summed rows R to a destination sample: row i goes to dst[i / R, i % R, :].
 // Row glue of the compact pipeline (stage split / concat of src/models.py:837-838,860-862 restricted
 // to the rows that matter); 16-B accesses, one row per F/4 lanes.
 __global__ __launch_bounds__(256) void gather2_kernel(const float* __restrict__ a, int64_t lda, int64_t bsa,
@@ -222,7 +227,12 @@ __global__ __launch_bounds__(256) void gather2_kernel(const float* __restrict__ 
       const int jb = map_b[i];
       if (jb >= 0) v = *reinterpret_cast<const float4*>(b_ + b * bsb + (int64_t)jb * ldb + c);
     }
-    *reinterpret_cast<float4*>(dst + b * bsd + (int64_t)i * ldd + c) = v;
+    if (sum_batch > 1) {
+      const int bq = i / sum_batch;
+      *reinterpret_cast<float4*>(dst + (int64_t)bq * bsd + (int64_t)(i - bq * sum_batch) * ldd + c) = v;
+    } else {
+      *reinterpret_cast<float4*>(dst + b * bsd + (int64_t)i * ldd + c) = v;
+    }
   }
 }
 
@@ -355,15 +365,22 @@ constexpr int kLossBlocks = 1024;
 
 extern "C" int gcl_assemble_input(const float* x, const float* gs, const float* ms, float* out, int64_t ldo,
                                   int32_t B, int32_t G, int32_t M, int32_t Cdyn, int32_t Cs, gcl_stream_t stream) {
-  GCL_CHECK_ARG(x && gs && ms && out, "assemble_input: null argument");
+  return gcl_assemble_input_tail(x, gs, ms, nullptr, 0, out, ldo, B, G, M, Cdyn, Cs, stream);
+}
+
+extern "C" int gcl_assemble_input_tail(const float* x, const float* gs, const float* ms, const float* tail, int32_t r,
+                                       float* out, int64_t ldo, int32_t B, int32_t G, int32_t M, int32_t Cdyn, int32_t Cs,
+                                       gcl_stream_t stream) {
+  GCL_CHECK_ARG(x && gs && (ms || r == M) && out, "assemble_input: null argument");
   GCL_CHECK_ARG(B > 0 && G > 0 && M >= 0 && Cdyn >= 0 && Cs >= 0 && ldo >= Cdyn + Cs, "assemble_input: bad shape");
+  GCL_CHECK_ARG(r >= 0 && r <= M && (r == 0 || tail), "assemble_input: tail rows r=%d outside [0, M=%d] or no tail", r, M);
   const int64_t total = (int64_t)B * (G + M) * (Cdyn + Cs);
   if (((Cdyn + Cs) & 3) == 0 && (ldo & 3) == 0 && gcl::aligned16(out))
     hipLaunchKernelGGL(assemble4_kernel, dim3(grid_for(total / 4, 8192)), dim3(256), 0, (hipStream_t)stream, x, gs, ms, out,
-                       ldo, B, G, M, Cdyn, Cs);
+                       ldo, B, G, M, Cdyn, Cs, tail, r);
   else
     hipLaunchKernelGGL(assemble_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, x, gs, ms, out,
-                     ldo, B, G, M, Cdyn, Cs);
+                     ldo, B, G, M, Cdyn, Cs, tail, r);
   GCL_CHECK_LAUNCH();
   return GCL_OK;
 }

@@ -141,7 +141,9 @@ def _lat_first_layer_bwd(lat, enc3, dz3, W, dW, acc_dw: bool, want_dx: bool, Pc=
     dzc = torch.empty(B, nc, Fo, dtype=torch.float32, device=dz3.device)
     if Md > 0:
         hip.gather2_rows(dz3, inv_a[G: G + Md], None, None, Md, B, out=dzc[:, :Md])
-    if r > 0:
+    if r > 1:
+        hip.gather2_rows(dz3, inv_fold, None, None, B * r, B, sum_batch=True, out=dzc[:, Md:], deal=r)
+    elif r == 1:
         tmp = hip.gather2_rows(dz3, inv_fold, None, None, B * r, B, sum_batch=True)
         hip.copy_rows(tmp.view(B, r, Fo), dzc[:, Md:])
     if Pc is None:  # the encoder rows behind the mesh latents
@@ -698,7 +700,9 @@ class MeshLatFn(torch.autograd.Function):
         out = land.buf if shared else torch.empty(B, ne, D, dtype=torch.float32, device=g.device)
         h = land.head if shared else 0  # rows below `head` were written by the decoder-input gather's backward
         hip.gather2_rows(g, inv_a[h:], None, None, ctx.gmd - h, B, out=out[:, h: ctx.gmd])
-        if ctx.r > 0:
+        if ctx.r > 1:  # the batch sums land r to a sample, straight in the tail rows
+            hip.gather2_rows(g, inv_fold, None, None, B * ctx.r, B, sum_batch=True, out=out[:, ctx.gmd:], deal=ctx.r)
+        elif ctx.r == 1:
             tmp = hip.gather2_rows(g, inv_fold, None, None, B * ctx.r, B, sum_batch=True)
             hip.copy_rows(tmp.view(B, ctx.r, D), out[:, ctx.gmd:])
         if shared:

@@ -68,6 +68,7 @@ _SIGNATURES = {
     "gcl_colsum": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
     "gcl_colsum_ws_bytes": (_sz, [_i64, _i32]),
     "gcl_assemble_input": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "gcl_assemble_input_tail": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "gcl_wmse_fwd_bwd": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f32, _f32, _vp,
                                    _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "gcl_ar_step_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -615,6 +616,10 @@ def assemble_input(x3, grid_static, mesh_static, tail3=None):
     M, Cs = mesh_static.shape
     x3 = x3.contiguous()
     out = torch.empty(B, G + M, Cdyn + Cs, dtype=torch.float32, device=x3.device)
+    if tail3 is not None and tail3.is_contiguous() and tail3.shape[2] == Cdyn + Cs:
+        _check(lib().gcl_assemble_input_tail(_p(x3), _p(grid_static), _p(mesh_static), _p(tail3), tail3.shape[1], _p(out),
+                                             Cdyn + Cs, B, G, M, Cdyn, Cs, _stream()))
+        return out
     _check(lib().gcl_assemble_input(_p(x3), _p(grid_static), _p(mesh_static), _p(out), Cdyn + Cs, B, G, M, Cdyn, Cs, _stream()))
     if tail3 is not None:
         copy_rows(tail3, out[:, G + M - tail3.shape[1]:, :])
@@ -665,18 +670,24 @@ def _pi(t):
     return t.data_ptr()
 
 
-def gather2_rows(a3, map_a, b3, map_b, nd: int, B: int, sum_batch: bool = False, out=None):
+def gather2_rows(a3, map_a, b3, map_b, nd: int, B: int, sum_batch: bool = False, out=None, deal: int = 0):
     """dst[b,i] = a3[b, map_a[i]] | b3[b or 0, map_b[i]] | 0   (see gcl_gather2_rows).
     a3 / b3: [Ba, na, F] with unit channel stride; Ba == 1 broadcasts over B.  `out`: a (possibly row-strided)
-    [B | 1, nd, F] destination, e.g. a row range of a larger buffer."""
+    [B | 1, nd, F] destination, e.g. a row range of a larger buffer.  sum_batch with deal = R > 1: the nd batch-summed
+    rows are stored R to a destination sample, out [nd / R, R, F] (possibly strided)."""
     F = a3.shape[-1]
-    if out is None:
-        out = torch.empty(1 if sum_batch else B, nd, F, dtype=torch.float32, device=a3.device)
-    assert out.shape == (1 if sum_batch else B, nd, F) and out.stride(2) == 1
+    if sum_batch and deal > 1:
+        assert out is not None and nd % deal == 0 and out.shape == (nd // deal, deal, F) and out.stride(2) == 1
+        flag = deal
+    else:
+        if out is None:
+            out = torch.empty(1 if sum_batch else B, nd, F, dtype=torch.float32, device=a3.device)
+        assert out.shape == (1 if sum_batch else B, nd, F) and out.stride(2) == 1
+        flag = 1 if sum_batch else 0
     bsa = a3.stride(0) if (a3.shape[0] > 1 or sum_batch) else 0
     bsb = 0 if b3 is None else (b3.stride(0) if b3.shape[0] > 1 else 0)
     _check(lib().gcl_gather2_rows(_p(a3), a3.stride(1), bsa, _pi(map_a), _p(b3), 0 if b3 is None else b3.stride(1),
-                                  bsb, _pi(map_b), _p(out), out.stride(1), out.stride(0), B, nd, F, 1 if sum_batch else 0, _stream()))
+                                  bsb, _pi(map_b), _p(out), out.stride(1), out.stride(0), B, nd, F, flag, _stream()))
     return out
 
 

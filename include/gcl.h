@@ -298,6 +298,12 @@ size_t gcl_colsum_ws_bytes(int64_t rows, int32_t F);
 int gcl_assemble_input(const float* x /*[B,G,Cdyn]*/, const float* grid_static /*[G,Cs]*/,
                        const float* mesh_static /*[M,Cs]*/, float* out, int64_t ldo, int32_t B,
                        int32_t G, int32_t M, int32_t Cdyn, int32_t Cs, gcl_stream_t stream);
+/* The same with the last r of the M mesh rows of every sample given whole, tail [B, r, Cdyn + Cs] contiguous (the
+ * per-sample folded rows of the compact pipeline: each sample carries different ones).  mesh_static may be NULL when
+ * r == M. */
+int gcl_assemble_input_tail(const float* x, const float* grid_static, const float* mesh_static, const float* tail,
+                            int32_t r, float* out, int64_t ldo, int32_t B, int32_t G, int32_t M, int32_t Cdyn,
+                            int32_t Cs, gcl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Residual add + weighted MSE and its gradient (src/train.py:203-213, 85-102).
@@ -430,7 +436,8 @@ int gcl_zero(void* ptr, size_t nbytes, gcl_stream_t stream);
 /* Row gather from up to two sources (stage glue of src/models.py:837-838,860-862 restricted to the
  * rows that matter):  dst[b,i,:] = a[b, map_a[i], :] if map_a[i] >= 0 (map_a NULL = identity), else
  * b[b, map_b[i], :] if map_b[i] >= 0, else 0.  A source with batch stride 0 is broadcast.
- * sum_batch != 0:  dst[0,i,:] = sum_b a[b, map_a[i], :]  (gradient of a broadcast source).
+ * sum_batch == 1:  dst[0,i,:] = sum_b a[b, map_a[i], :]  (gradient of a broadcast source);
+ * sum_batch = R > 1: the same sums, row i stored at dst[i / R, i % R, :] (R rows dealt to each destination sample).
  * Maps are int32 device arrays of length nd; F % 4 == 0 and 16-B aligned rows. */
 int gcl_gather2_rows(const float* a, int64_t lda, int64_t bsa, const int32_t* map_a, const float* b,
                      int64_t ldb, int64_t bsb, const int32_t* map_b, float* dst, int64_t ldd, int64_t bsd,

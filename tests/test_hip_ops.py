@@ -526,6 +526,21 @@ def test_layernorm_fwd_through_row_map(hip, B, n, F, ldo):
     assert (out[:, :head] == 7.0).all() and (out[..., F:] == 7.0).all()
 
 
+def test_gather2_rows_batch_sum_dealt_to_samples(hip):
+    """gcl_gather2_rows with sum_batch = R > 1: row i of the nd batch-summed rows is stored at dst[i / R, i % R] (the
+    gradient of the shared rows of the compact pipeline lands R to a sample, straight in a row range of a larger buffer)."""
+    B, n, F, R = 5, 300, 64, 7
+    gen = torch.Generator().manual_seed(2)
+    a = rnd(B, n, F, seed=1)
+    m = torch.randint(-1, n, (B * R,), generator=gen).to(torch.int32)
+    ref = torch.where((m >= 0)[:, None], a.sum(0)[m.clamp(min=0).long()], torch.zeros(1, F))
+    flat = hip.gather2_rows(a.to(DEV), m.to(DEV), None, None, B * R, B, sum_batch=True)
+    assert rel(flat[0], ref) < 1e-6
+    buf = torch.full((B, 4 + R, F), 3.0, device=DEV)
+    hip.gather2_rows(a.to(DEV), m.to(DEV), None, None, B * R, B, sum_batch=True, out=buf[:, 4:], deal=R)
+    assert torch.equal(buf[:, 4:].reshape(B * R, F), flat[0]) and (buf[:, :4] == 3.0).all()
+
+
 @pytest.mark.parametrize("rows,F", [(1000, 64), (13, 33), (5000, 128)])
 def test_colsum(hip, rows, F):
     x = rnd(rows, F, seed=1)
