@@ -126,13 +126,13 @@ _LN_COLSUM = os.environ.get("GCL_NO_LN_COLSUM", "0") in ("0", "")
 _ROWS_OUT = os.environ.get("GCL_NO_ROWS_OUT", "0") in ("0", "")
 
 
-def _lat_first_layer_bwd(lat, enc3, dz3, W, dW, acc_dw: bool, want_dx: bool, Pc=None):
+def _lat_first_layer_bwd(lat, enc3, dz3, W, dW, acc_dw: bool, want_dx: bool, Pc=None, enc_shape=None):
     """Dense backward of a first processor layer whose input was read through a LatSource: dz3 [B, M, D'] is the
     gradient of the layer's transformed mesh rows (GCN: A^T dp, GAT: dh).  Returns the gradient of the encoder output
     [B, ne, D] (or None when the shared landing buffer took it / no gradient is wanted); dW is written / accumulated in
     place.  Pc: the compact encoder rows [B, Md + r, D] when the forward already copied them."""
     _, _, inv_a, inv_fold = lat.maps
-    B, ne, D = enc3.shape
+    B, ne, D = enc_shape if enc3 is None else enc3.shape  # (enc3 may be None when Pc is given: only its shape is needed)
     G, Md, r = lat.G, lat.Md, lat.r
     nc = Md + r
     Fo = dz3.shape[-1]
@@ -444,8 +444,8 @@ class GATLayerFn(torch.autograd.Function):
         if ctx.lat is not None:
             # fold dh [B, M, H*C] back onto the compact rows and run the dense backward there (LatSource)
             dW = G.dst[1] if G.dst[1] is not None else torch.zeros_like(W)
-            dx = _lat_first_layer_bwd(ctx.lat, torch.empty(ctx.enc_shape, device="meta"), dh, W.detach(), dW, G.acc[1],
-                                      ctx.needs_input_grad[0], Pc=ctx.x3)
+            dx = _lat_first_layer_bwd(ctx.lat, None, dh, W.detach(), dW, G.acc[1], ctx.needs_input_grad[0], Pc=ctx.x3,
+                                      enc_shape=tuple(ctx.enc_shape))
             return (dx, None, None, None, None) + G.out()
         dh2 = dh.view(B * n, -1)
         inp = ctx.x3.view(B * n, -1)
