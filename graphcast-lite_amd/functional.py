@@ -468,11 +468,30 @@ class GATLayerFn(torch.autograd.Function):
 
 
 class LayerNormFn(torch.autograd.Function):
+    """Node-mode LayerNorm.  When the owner carries a GradLanding (`_grad_src`: the final LayerNorm of a GAT processor
+    inside WeatherPrediction.forward) it takes part in the same two channels as GCNStackFn's fused LayerNorm: the
+    output rows the decoder reads go straight into the decoder's input (dec_buf), and the backward reads its gradient
+    through the decoder-input gather's row map instead of a zero-filled dense tensor."""
+
     @staticmethod
     def forward(ctx, x, owner, eps, gamma, beta):
         x2 = hip.rows2d(x.detach())
+        land = getattr(owner, "_grad_src", None)
+        ctx.land = None
+        if land is not None:
+            owner._grad_src = None
+            if x.dim() == 3:
+                ctx.land = land
+                land.proc_ready = True
+        ctx.params = (gamma, beta)
+        if ctx.land is not None and land.dec_buf is not None and land.dec_buf.shape[2] == x.shape[-1]:
+            B, n, F = x.shape
+            stats = hip.layernorm_fwd_map(x2, gamma.detach(), beta.detach(), eps, land.dec_buf, land.dec_map)
+            land.dec_filled = True
+            ctx.x2, ctx.stats = x2, stats
+            return x2.new_zeros(()).expand(B, n, F)
         y, stats = hip.layernorm_fwd(x2, gamma.detach(), beta.detach(), eps)
-        ctx.x2, ctx.stats, ctx.params = x2, stats, (gamma, beta)
+        ctx.x2, ctx.stats = x2, stats
         return y.view(x.shape)
 
     @staticmethod
@@ -481,7 +500,17 @@ class LayerNormFn(torch.autograd.Function):
         G = _Grads([gamma, beta], list(ctx.needs_input_grad[3:]))
         dg = G.dst[0] if G.dst[0] is not None else torch.zeros_like(gamma)
         db = G.dst[1] if G.dst[1] is not None else torch.zeros_like(beta)
-        dx = hip.layernorm_bwd(hip.rows2d(dy), ctx.x2, gamma.detach(), ctx.stats, dg, db, G.acc[0] and G.acc[1])
+        land, dy_map = ctx.land, None
+        if land is not None and land.proc_src is not None:
+            if all(st == 0 for st in dy.stride()):
+                dy_map = (land.proc_src, land.proc_map)  # the token: the gradient is the gather's, through its row map
+            else:  # someone else also sent gradient here: materialise the gather's part and add (see GCNStackFn.backward)
+                src, pmap = land.proc_src, land.proc_map
+                dy = _flat3(dy) + hip.gather2_rows(src, pmap, None, None, dy.shape[-2], src.shape[0])
+            land.proc_src = land.proc_map = None
+            land.proc_ready = False
+        dx = hip.layernorm_bwd(None if dy_map is not None else hip.rows2d(dy), ctx.x2, gamma.detach(), ctx.stats, dg, db,
+                               G.acc[0] and G.acc[1], dy_map=dy_map)
         return (dx.view(dy.shape), None, None) + G.out()
 
 

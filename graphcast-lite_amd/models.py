@@ -436,6 +436,8 @@ class GraphLayer(nn.Module):
                     slope = self._slope if self._slope is not None else self.const_slope
                     act = self.act_kind
                 elif isinstance(layer, LayerNorm):
+                    if layer is ln and fuse_ln:
+                        layer._grad_src = kwargs.get("_grad_src")  # functional.GradLanding (picked up by LayerNormFn)
                     X = layer(X)
             return X
 
@@ -444,6 +446,8 @@ class GraphLayer(nn.Module):
                 if isinstance(layer, SparseGATConv):
                     X, (edge_index, _) = layer.forward(X, edge_index, attention_threshold, **kwargs)
                 elif isinstance(layer, LayerNorm):
+                    if layer is ln and fuse_ln:
+                        layer._grad_src = kwargs.get("_grad_src")  # functional.GradLanding (picked up by LayerNormFn)
                     X = layer(X)
             return X, edge_index
         raise NotImplementedError(f"Layer type {self.layer_type} not supported.")
@@ -797,8 +801,12 @@ class WeatherPrediction(nn.Module):
             mesh_lat = Gather2Fn.apply(enc_c, inv, c.maps_mesh, M, B)                   # [B, M, D]
         if self.using_sparse_gat:
             pg = self._processing_graph_tiled() if c.perm is not None else self.processing_graph
+            if land is not None and self._ln_into_decoder_input and self._latents_discarded and not squeeze:
+                land.dec_buf = torch.empty(B, G + c.U, enc_c.shape[-1], dtype=torch.float32, device=enc_c.device)
+                land.dec_map = maps_dec[3]
             processed, new_edge_index = self.processor.forward(
-                X=mesh_lat, edge_index=pg, attention_threshold=attention_threshold, **kwargs)
+                X=mesh_lat, edge_index=pg, attention_threshold=attention_threshold,
+                **({"_grad_src": land} if land is not None else {}), **kwargs)
             self.processing_graph = self._processing_graph_from_tiled(new_edge_index) if c.perm is not None else new_edge_index
         elif self.using_interaction_net:
             processed = self.processor.forward(X=mesh_lat, edge_index=self.processing_graph,
@@ -807,7 +815,8 @@ class WeatherPrediction(nn.Module):
         else:
             pg = self._processing_graph_tiled() if c.perm is not None else self.processing_graph
             if (land is not None and self._ln_into_decoder_input and self._latents_discarded
-                    and self.processor.graph_layer.layer_type == GraphLayerType.ConvGCN and not squeeze):
+                    and self.processor.graph_layer.layer_type in (GraphLayerType.ConvGCN, GraphLayerType.GATConv)
+                    and not squeeze):
                 # the processor's output is only consumed by the decoder-input gather: its final LayerNorm writes the
                 # rows the decoder reads straight into the decoder's input (functional.GradLanding.dec_buf)
                 land.dec_buf = torch.empty(B, G + c.U, enc_c.shape[-1], dtype=torch.float32, device=enc_c.device)

@@ -184,14 +184,15 @@ def test_latents_through_row_table_equal_materialised(name, levels, B):
         assert d <= 1e-5 * float(gt[n_].double().norm()) + 1e-7 * gn, n_
 
 
-def test_processor_layernorm_into_decoder_input_equals_gather():
+@pytest.mark.parametrize("name", ["baseline", "attention"])
+def test_processor_layernorm_into_decoder_input_equals_gather(name):
     """forward(): nobody sees the processor's output, so its final LayerNorm writes only the rows the decoder reads,
     straight into the decoder's input (gcl_layernorm_fwd_map, functional.GradLanding.dec_buf) and the gather copies
     just the grid rows.  Against the same model with the dense LayerNorm + gather: prediction bit-identical, gradients
     identical too (the backward is the same code on the same saved tensors)."""
     from graphcast_lite_amd.train import batch_loss
 
-    cfg, m, o = make_pair("baseline", [3, 5])
+    cfg, m, o = make_pair(name, [3, 5])
     X, y = data(cfg, m._num_grid_nodes, 5)
     assert m._ln_into_decoder_input and m._grad_landing
     out_m = m(X.to(DEV))
@@ -331,13 +332,14 @@ def test_train_step_with_frozen_processor_and_rollout(monkeypatch):
         assert torch.equal(p, before[n_]), f"frozen parameter {n_} moved"
 
 
-def test_second_consumer_of_the_processor_output_keeps_its_gradient():
+@pytest.mark.parametrize("name", ["baseline", "attention"])
+def test_second_consumer_of_the_processor_output_keeps_its_gradient(name):
     """`WeatherPrediction.forward` lets the decoder-input gather hand the processor's output gradient over as a
     stride-0 token + row map (functional.GradLanding).  If anything else ALSO consumes the processor's output, autograd
     sums its gradient with the token: the stack's backward must notice that the incoming gradient is no longer the
     token and add the gather's part to it instead of dropping the other consumer's share."""
-    cfg, m1, _ = make_pair("baseline", [1, 2])
-    _, m2, _ = make_pair("baseline", [1, 2])
+    cfg, m1, _ = make_pair(name, [1, 2])
+    _, m2, _ = make_pair(name, [1, 2])
     X, _ = data(cfg, m1._num_grid_nodes, 3)
     m2._grad_landing = False  # plain autograd accumulation: the reference behaviour
     grads = []
