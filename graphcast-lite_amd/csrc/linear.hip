@@ -1506,11 +1506,18 @@ static int dw_block(const float* dy, int64_t lddy, const float* x, int64_t ldx, 
 #undef GCL_DW2
 #undef GCL_DW3
   GCL_CHECK_LAUNCH();
-  for (int ct = 0; ct < nct; ++ct) {
-    const int fi = Fin - ct * 128 < 128 ? Fin - ct * 128 : 128;
-    int rc = gcl::launch_reduce_parts(part + ct * tile_stride, (int)nblk, (int64_t)FoutP * FinP, FinP, dW + ct * 128,
-                                      (int)lddw, Fout, fi, accumulate, st);
-    if (rc) return rc;
+  // final pass: the input chunks of a wide layer three to a launch (one segment each: chunk ct's records start
+  // ct * tile_stride floats into the workspace) - a 256-wide layer used to end in two of these launches per call
+  for (int ct = 0; ct < nct; ct += 3) {
+    RedSeg seg[3] = {{nullptr, 0, 0, 1, 0, 0, 0}, {nullptr, 0, 0, 1, 0, 0, 0}, {nullptr, 0, 0, 1, 0, 0, 0}};
+    for (int q = 0; q < 3 && ct + q < nct; ++q) {
+      const int c = ct + q;
+      const int fi = Fin - c * 128 < 128 ? Fin - c * 128 : 128;
+      GCL_CHECK_ARG((int64_t)c * tile_stride < ((int64_t)1 << 31), "dense_bwd_dw: partial workspace offset overflows");
+      seg[q] = RedSeg{dW + c * 128, (int32_t)(c * tile_stride), Fout * FinP, FinP, fi, (int32_t)lddw, accumulate};
+    }
+    launch_reduce_multi(part, (int)nblk, (int64_t)FoutP * FinP, seg[0], seg[1], seg[2], st);
+    GCL_CHECK_LAUNCH();
   }
   if (db) return gcl::launch_reduce_parts(dbpart, (int)nblk, (int64_t)FoutP, FoutP, db, Fout, 1, Fout, accumulate, st);
   return GCL_OK;
