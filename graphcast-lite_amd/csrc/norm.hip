@@ -197,12 +197,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR, c0 = l * 4;
   float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  if (c0 < F)
-    for (int64_t row = (int64_t)blockIdx.x * RPB + wave * RPW + sub; row < rows; row += (int64_t)gridDim.x * RPB) {
+  if (c0 < F) {
+    // four rows in flight per thread (one load per trip left a wave with a single 16-byte load outstanding: 2.7 TB/s at
+    // 128 columns); the sums are taken in the same row order as before
+    const int64_t step = (int64_t)gridDim.x * RPB;
+    int64_t row = (int64_t)blockIdx.x * RPB + wave * RPW + sub;
+    for (; row + 3 * step < rows; row += 4 * step) {
+      float a0, a1, a2, a3, b0, b1, b2, b3, c1_, c2_, c3_, c4_, d0, d1, d2, d3;
+      load4(X + row * ldx + c0, c0, F, vx, a0, a1, a2, a3);
+      load4(X + (row + step) * ldx + c0, c0, F, vx, b0, b1, b2, b3);
+      load4(X + (row + 2 * step) * ldx + c0, c0, F, vx, c1_, c2_, c3_, c4_);
+      load4(X + (row + 3 * step) * ldx + c0, c0, F, vx, d0, d1, d2, d3);
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+      s0 += b0; s1 += b1; s2 += b2; s3 += b3;
+      s0 += c1_; s1 += c2_; s2 += c3_; s3 += c4_;
+      s0 += d0; s1 += d1; s2 += d2; s3 += d3;
+    }
+    for (; row < rows; row += step) {
       float x0, x1, x2, x3;
       load4(X + row * ldx + c0, c0, F, vx, x0, x1, x2, x3);
       s0 += x0; s1 += x1; s2 += x2; s3 += x3;
     }
+  }
   float* r = red[wave * RPW + sub];
   r[c0] = s0; r[c0 + 1] = s1; r[c0 + 2] = s2; r[c0 + 3] = s3;
   __syncthreads();
