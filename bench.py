@@ -437,7 +437,11 @@ def main():
                         achieved_gather_counted_gbs=B * (per_sample + 4 * Ep * F) / (roof["avg_launch_us"] * 1e-6) / 1e9)
             if fused is not None and roof is not fused:
                 # same algorithmic bytes (X in, Y out, CSR): the one-kernel layer replaces linear + aggregate
-                roof["gcn_layer_one_kernel"] = dict(fused, traffic=traffic_of(fname))
+                roof["gcn_layer_one_kernel"] = dict(
+                    fused, traffic=traffic_of(fname),
+                    note="average over the mesh layers of a step; where the compact pipeline is on, the FIRST of them reads its "
+                         "input rows through a row table from the encoder output (batch-invariant rows from one shared copy), "
+                         "so it moves fewer bytes than the algorithmic count of a dense [B, n, F] input")
     if is_gat and probe is not None and probe.events.get("gat_fwd"):
         # GATConv / SparseGATConv processor: the attention aggregation kernel (scores + neighbour softmax + weighted sum).
         # Algorithmic bytes per sample: the GCN aggregation's + 8 n (a_src, a_dst) + 4 E' H when alpha is kept
